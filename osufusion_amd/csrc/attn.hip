@@ -1,0 +1,567 @@
+// MQA flash attention for the denoiser's self-attention (unet.py:125-141, attention.py:84-101), gfx950.
+//   q: [B*N][ldq] bf16, head h at columns h*64..h*64+63 ; k, v: [B*N][ldk/ldv] bf16, ONE kv head (64 columns)
+//   softmax(q k^T / 8) v, non-causal, no mask.  bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 softmax/accumulate.
+// The 16 query heads share one K/V head, so a workgroup stages each 64-key K/V tile in LDS once and all of
+// its 8 waves (= 8 (head, 32-query block) pairs) consume it: 1/16 of the K/V bytes of the reference's
+// repeat()-ed tensors.  Everything is computed "transposed" (S^T = K Q^T, O^T = V^T P^T) so that a query row
+// lives on one lane: row max / row sum / rescale are lane-local (one xor-32 shuffle), and the S^T accumulator
+// is directly the B operand of the PV product (k order permuted consistently on the V^T side, read with
+// ds_read_b64_tr_b16 from the row-major V tile).
+// Backward = two kernels without atomics: dQ (query-stationary, same loop as forward) and dK/dV
+// (key-stationary: a wave owns 32 keys, dK^T/dV^T stay in registers while it sweeps heads x query blocks).
+#include "common.hpp"
+
+static constexpr int D = 64;                      // head dim (bytes per tile row = 128)
+static constexpr float kLog2e = 1.4426950408889634f;
+
+// tile image [rows][64 bf16]: 16-B chunk index xor-swizzled so that BOTH ds_read_b128 row reads and
+// ds_read_b64_tr_b16 column reads are bank-conflict free (f differs in bit 2 between rows r and r+2).
+__device__ __forceinline__ int tile_off(int row, int colbyte) {
+  const int x = (row >> 1) & 7;
+  const int f = ((x & 1) << 2) | (x >> 1);
+  return row * 128 + ((((colbyte >> 4) ^ f) << 4) | (colbyte & 15));
+}
+
+__device__ __forceinline__ bf16x8 lds_row_frag(const char* tile, int row, int chunk) {
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tile + tile_off(row, chunk * 16)));
+}
+
+// A-operand fragment of a TRANSPOSED tile read: element e of lane (r = lane&31, h = lane>>5) =
+//   tile[rowbase + 8*(e>>2) + 4*h + (e&3)][colbase + r]      (the k order of an accumulator used as B operand)
+__device__ __forceinline__ bf16x8 lds_tr_frag(const char* tile, int rowbase, int colbase, int lane) {
+  const int lh = lane >> 5, cb = ((lane >> 4) & 1) * 16, ip = lane & 15, tq = ip >> 2, tp = ip & 3;
+  const int colbyte = (colbase + cb + 4 * tp) * 2;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + tile_off(rowbase + 4 * lh + tq, colbyte)));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + tile_off(rowbase + 8 + 4 * lh + tq, colbyte)));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// registers 8*sub .. 8*sub+7 of a 32x32 accumulator -> bf16x8 B-operand fragment (k order permuted, see above)
+__device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int sub) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = pack_bf16x2(a[8 * sub + 2 * i], a[8 * sub + 2 * i + 1]);
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+struct AttnArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v;
+  long ldq, ldk, ldv;
+  void* o; long ldo; int o_is_f32;              // forward output (bf16-rounded values; stored as bf16 or f32)
+  float* lse2;                                  // [B][H][N] log2-domain logsumexp of (s * scale * log2e)
+  const bf16_t* dout; long lddo;                // backward
+  const float* delta;                           // [B][H][N]
+  float* dq; long lddq;                         // fp32 [B*N][lddq], head h at h*64
+  float* dk; float* dv; long lddk;              // fp32 [B*N][lddk]
+  int B, H, N;
+  float scale;
+};
+
+// cooperative K/V tile stage: 512 threads, one 16-B chunk of K and one of V each (64 keys x 128 B)
+struct KVStage {
+  u32x4 rk, rv;
+  __device__ __forceinline__ void load(const AttnArgs& a, int b, int key0, int tid) {
+    const int row = tid >> 3, chunk = tid & 7;
+    const int key = key0 + row;
+    u32x4 z = {0u, 0u, 0u, 0u};
+    rk = z; rv = z;
+    if (key < a.N) {
+      const long m = (long)b * a.N + key;
+      rk = *reinterpret_cast<const u32x4*>(a.k + m * a.ldk + chunk * 8);
+      rv = *reinterpret_cast<const u32x4*>(a.v + m * a.ldv + chunk * 8);
+    }
+  }
+  __device__ __forceinline__ void store(char* ks, char* vs, int tid) const {
+    const int row = tid >> 3, chunk = tid & 7;
+    *reinterpret_cast<u32x4*>(ks + tile_off(row, chunk * 16)) = rk;
+    *reinterpret_cast<u32x4*>(vs + tile_off(row, chunk * 16)) = rv;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void mqa_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][K 8K | V 8K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y;
+  const int nqb = (a.N + 31) >> 5;
+  const int vb = blockIdx.x * 8 + wave;
+  const bool active = vb < nqb * a.H;
+  const int h = active ? vb % a.H : 0, pb = active ? vb / a.H : 0;
+  const int qrow = pb * 32 + lr;
+  const bool qok = active && qrow < a.N;
+  const float c = a.scale * kLog2e;
+
+  bf16x8 qf[4];
+  {
+    const bf16_t* qp = a.q + ((long)b * a.N + qrow) * a.ldq + h * D;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 z = {0u, 0u, 0u, 0u};
+      if (qok) z = *reinterpret_cast<const u32x4*>(qp + 16 * ks + 8 * lh);
+      qf[ks] = __builtin_bit_cast(bf16x8, z);
+    }
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (a.N + 63) >> 6;
+  KVStage st;
+  st.load(a, b, 0, tid);
+  st.store(smem, smem + 8192, tid);
+  __syncthreads();
+  for (int j = 0; j < ntiles; ++j) {
+    const char* ks_ = smem + (j & 1) * 16384;
+    const char* vs_ = ks_ + 8192;
+    if (j + 1 < ntiles) st.load(a, b, (j + 1) * 64, tid);
+    // S^T = K Q^T  (two 32-key tiles)
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(ks_, kt * 32 + lr, 2 * ks + lh), qf[ks], s[kt], 0, 0, 0);
+    }
+    if ((j + 1) * 64 > a.N) {                      // ragged last tile: mask keys >= N
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int key = j * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= a.N) s[kt][r] = -INFINITY;
+        }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * c);
+    const float alpha = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = fast_exp2(s[kt][r] * c - m_new);
+        s[kt][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    // O^T += V^T P^T
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const bf16x8 pf = acc_to_frag(s[s4 >> 1], s4 & 1);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(vs_, (s4 >> 1) * 32 + (s4 & 1) * 16, dt * 32, lane), pf, o[dt], 0, 0, 0);
+    }
+    if (j + 1 < ntiles) st.store(smem + ((j + 1) & 1) * 16384, smem + ((j + 1) & 1) * 16384 + 8192, tid);
+    __syncthreads();
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (qok) {
+    const float inv = 1.f / l_tot;
+    if (lh == 0) a.lse2[((long)b * a.H + h) * a.N + qrow] = m_run + __builtin_amdgcn_logf(l_tot);   // v_log_f32 = log2
+    const long m = (long)b * a.N + qrow;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = round_bf16(o[dt][4 * g + e] * inv);
+        const int d0 = dt * 32 + 8 * g + 4 * lh;
+        if (a.o_is_f32) store4(reinterpret_cast<float*>(a.o) + m * a.ldo + h * D + d0, v4);
+        else store4(reinterpret_cast<bf16_t*>(a.o) + m * a.ldo + h * D + d0, v4);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward, dQ: query-stationary.  dQ^T[d][q] = sum_key K^T[d][key] * dS^T[key][q]
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void mqa_bwd_dq_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y;
+  const int nqb = (a.N + 31) >> 5;
+  const int vb = blockIdx.x * 8 + wave;
+  const bool active = vb < nqb * a.H;
+  const int h = active ? vb % a.H : 0, pb = active ? vb / a.H : 0;
+  const int qrow = pb * 32 + lr;
+  const bool qok = active && qrow < a.N;
+  const float c = a.scale * kLog2e;
+
+  bf16x8 qf[4], dof[4];
+  {
+    const bf16_t* qp = a.q + ((long)b * a.N + qrow) * a.ldq + h * D;
+    const bf16_t* dp = a.dout + ((long)b * a.N + qrow) * a.lddo + h * D;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 z = {0u, 0u, 0u, 0u}, z2 = {0u, 0u, 0u, 0u};
+      if (qok) { z = *reinterpret_cast<const u32x4*>(qp + 16 * ks + 8 * lh); z2 = *reinterpret_cast<const u32x4*>(dp + 16 * ks + 8 * lh); }
+      qf[ks] = __builtin_bit_cast(bf16x8, z);
+      dof[ks] = __builtin_bit_cast(bf16x8, z2);
+    }
+  }
+  const long sidx = ((long)b * a.H + h) * a.N + qrow;
+  const float L2 = qok ? a.lse2[sidx] : INFINITY;
+  const float dl = qok ? a.delta[sidx] : 0.f;
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int ntiles = (a.N + 63) >> 6;
+  KVStage st;
+  st.load(a, b, 0, tid);
+  st.store(smem, smem + 8192, tid);
+  __syncthreads();
+  for (int j = 0; j < ntiles; ++j) {
+    const char* ks_ = smem + (j & 1) * 16384;
+    const char* vs_ = ks_ + 8192;
+    if (j + 1 < ntiles) st.load(a, b, (j + 1) * 64, tid);
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[kt][r] = 0.f; dp[kt][r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(ks_, kt * 32 + lr, 2 * ks + lh), qf[ks], s[kt], 0, 0, 0);
+        dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(vs_, kt * 32 + lr, 2 * ks + lh), dof[ks], dp[kt], 0, 0, 0);
+      }
+    }
+    // dS^T = P^T * (dP^T - delta) * scale   (zero K rows make masked keys contribute nothing)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = fast_exp2(s[kt][r] * c - L2);
+        s[kt][r] = p * (dp[kt][r] - dl) * a.scale;
+      }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const bf16x8 df = acc_to_frag(s[s4 >> 1], s4 & 1);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(ks_, (s4 >> 1) * 32 + (s4 & 1) * 16, dt * 32, lane), df, acc[dt], 0, 0, 0);
+    }
+    if (j + 1 < ntiles) st.store(smem + ((j + 1) & 1) * 16384, smem + ((j + 1) & 1) * 16384 + 8192, tid);
+    __syncthreads();
+  }
+  if (qok) {
+    const long m = (long)b * a.N + qrow;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v4[4] = {acc[dt][4 * g], acc[dt][4 * g + 1], acc[dt][4 * g + 2], acc[dt][4 * g + 3]};
+        store4(a.dq + m * a.lddq + h * D + dt * 32 + 8 * g + 4 * lh, v4);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward, dK/dV: key-stationary.  A wave owns 32 keys; the workgroup (8 waves = 256 keys) sweeps every
+// (head, 32-query block) pair, staging Q / dO / lse / delta of the pair in LDS for all waves.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void mqa_bwd_dkv_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][Q 4K | dO 4K | lse 128 | delta 128]
+  constexpr int kStage = 4096 + 4096 + 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y;
+  const int key = blockIdx.x * 256 + wave * 32 + lr;
+  const bool kok = key < a.N;
+  const float c = a.scale * kLog2e;
+  const int nqb = (a.N + 31) >> 5;
+  const int niter = nqb * a.H;
+
+  bf16x8 kf[4], vf[4];
+  {
+    const long m = (long)b * a.N + key;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 z = {0u, 0u, 0u, 0u}, z2 = {0u, 0u, 0u, 0u};
+      if (kok) { z = *reinterpret_cast<const u32x4*>(a.k + m * a.ldk + 16 * ks + 8 * lh); z2 = *reinterpret_cast<const u32x4*>(a.v + m * a.ldv + 16 * ks + 8 * lh); }
+      kf[ks] = __builtin_bit_cast(bf16x8, z);
+      vf[ks] = __builtin_bit_cast(bf16x8, z2);
+    }
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+
+  // stage loader: threads 0..255 -> Q chunk, 256..511 -> dO chunk; threads 0..31 lse, 32..63 delta
+  u32x4 rt; float rs = 0.f;
+  auto load_stage = [&](int it) {
+    const int h = it % a.H, pb = it / a.H;
+    const int t = tid & 255, row = t >> 3, chunk = t & 7;
+    const int qrow = pb * 32 + row;
+    u32x4 z = {0u, 0u, 0u, 0u};
+    rt = z;
+    if (qrow < a.N) {
+      const long m = (long)b * a.N + qrow;
+      rt = (tid < 256) ? *reinterpret_cast<const u32x4*>(a.q + m * a.ldq + h * D + chunk * 8)
+                       : *reinterpret_cast<const u32x4*>(a.dout + m * a.lddo + h * D + chunk * 8);
+    }
+    if (tid < 64) {
+      const int qr = pb * 32 + (tid & 31);
+      const long sidx = ((long)b * a.H + h) * a.N + qr;
+      if (tid < 32) rs = qr < a.N ? a.lse2[sidx] : INFINITY;
+      else rs = qr < a.N ? a.delta[sidx] : 0.f;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    char* base = smem + buf * kStage;
+    const int t = tid & 255, row = t >> 3, chunk = t & 7;
+    *reinterpret_cast<u32x4*>(base + (tid < 256 ? 0 : 4096) + tile_off(row, chunk * 16)) = rt;
+    if (tid < 64) reinterpret_cast<float*>(base + 8192)[tid] = rs;
+  };
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int it = 0; it < niter; ++it) {
+    const char* qs = smem + (it & 1) * kStage;
+    const char* dos = qs + 4096;
+    const float* ls = reinterpret_cast<const float*>(qs + 8192);
+    if (it + 1 < niter) load_stage(it + 1);
+    // S[q][key] = Q K^T ; dP[q][key] = dO V^T    (q rows in registers, key on the lane)
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(qs, lr, 2 * ks + lh), kf[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(dos, lr, 2 * ks + lh), vf[ks], dp, 0, 0, 0);
+    }
+    f32x16 ds;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(ls + 8 * g + 4 * lh);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(ls + 32 + 8 * g + 4 * lh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        float p = fast_exp2(s[r] * c - l4[e]);
+        s[r] = p;
+        ds[r] = p * (dp[r] - d4[e]) * a.scale;
+      }
+    }
+    // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 pf = acc_to_frag(s, s2);
+      const bf16x8 df = acc_to_frag(ds, s2);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(dos, s2 * 16, dt * 32, lane), pf, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(qs, s2 * 16, dt * 32, lane), df, dk[dt], 0, 0, 0);
+      }
+    }
+    if (it + 1 < niter) store_stage((it + 1) & 1);
+    __syncthreads();
+  }
+  if (kok) {
+    const long m = (long)b * a.N + key;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = dt * 32 + 8 * g + 4 * lh;
+        float k4[4] = {dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]};
+        float v4[4] = {dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]};
+        store4(a.dk + m * a.lddk + d0, k4);
+        store4(a.dv + m * a.lddk + d0, v4);
+      }
+  }
+}
+
+// delta[b][h][n] = sum_d dO[b,n,h,d] * O[b,n,h,d]   (8 lanes per (row, head), 8 elements each)
+template <typename TO>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* dout, long lddo, const TO* o, long ldo, float* delta,
+                                                         int B, int H, int N) {
+  const long total = (long)B * N * H * 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total + 7; idx += (long)gridDim.x * blockDim.x) {
+    const bool ok = idx < total;
+    const long rh = ok ? idx >> 3 : 0;
+    const int sub = (int)(idx & 7);
+    const long m = rh / H;
+    const int h = (int)(rh - m * H);
+    float s = 0.f;
+    if (ok) {
+      float x[8], y[8];
+      load8(dout + m * lddo + h * D + sub * 8, x);
+      load8(o + m * ldo + h * D + sub * 8, y);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += x[e] * y[e];
+    }
+    s = group_sum<8>(s);
+    if (ok && sub == 0) {
+      const long bb = m / N, n = m - bb * N;
+      delta[(bb * H + h) * N + n] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// RoPE (attention.py:33-58, utils.py:25-32; half-split layout) fused with the bf16 cast of q, k, v
+//   in : [M][ld_in]  T (q heads | kv heads k | kv heads v), tab: [N][32] cos, [N][32] sin (fp32)
+//   out: [M][ld_out] bf16, same column layout
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rope_cast_kernel(const T* in, long ld_in, bf16_t* out, long ld_out, const float* cosb,
+                                                        const float* sinb, int M, int N, int n_rot_heads, int n_heads_total) {
+  // one thread: 8 columns d0..d0+7 (d0 < 32) of one head and their partners d0+32..; 4 threads per (row, head)
+  const long total = (long)M * n_heads_total * 4;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int sub = (int)(idx & 3);
+    const long rh = idx >> 2;
+    const long m = rh / n_heads_total;
+    const int hd = (int)(rh - m * n_heads_total);
+    const int n = (int)(m % N);
+    float x1[8], x2[8];
+    load8(in + m * ld_in + hd * D + sub * 8, x1);
+    load8(in + m * ld_in + hd * D + 32 + sub * 8, x2);
+    if (hd < n_rot_heads) {
+      float cs[8], sn[8];
+      load8(cosb + (long)n * 32 + sub * 8, cs);
+      load8(sinb + (long)n * 32 + sub * 8, sn);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a1 = x1[e] * cs[e] - x2[e] * sn[e];
+        const float a2 = x2[e] * cs[e] + x1[e] * sn[e];
+        x1[e] = a1; x2[e] = a2;
+      }
+    }
+    store8(out + m * ld_out + hd * D + sub * 8, x1);
+    store8(out + m * ld_out + hd * D + 32 + sub * 8, x2);
+  }
+}
+
+// inverse rotation of fp32 grads -> T:  dx1 = dy1*cos + dy2*sin ; dx2 = dy2*cos - dy1*sin
+template <typename T>
+__global__ __launch_bounds__(256) void rope_bwd_kernel(const float* in, long ld_in, T* out, long ld_out, const float* cosb,
+                                                       const float* sinb, int M, int N, int n_rot_heads, int n_heads_total) {
+  const long total = (long)M * n_heads_total * 4;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int sub = (int)(idx & 3);
+    const long rh = idx >> 2;
+    const long m = rh / n_heads_total;
+    const int hd = (int)(rh - m * n_heads_total);
+    const int n = (int)(m % N);
+    float y1[8], y2[8];
+    load8(in + m * ld_in + hd * D + sub * 8, y1);
+    load8(in + m * ld_in + hd * D + 32 + sub * 8, y2);
+    if (hd < n_rot_heads) {
+      float cs[8], sn[8];
+      load8(cosb + (long)n * 32 + sub * 8, cs);
+      load8(sinb + (long)n * 32 + sub * 8, sn);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a1 = y1[e] * cs[e] + y2[e] * sn[e];
+        const float a2 = y2[e] * cs[e] - y1[e] * sn[e];
+        y1[e] = a1; y2[e] = a2;
+      }
+    }
+    store8(out + m * ld_out + hd * D + sub * 8, y1);
+    store8(out + m * ld_out + hd * D + 32 + sub * 8, y2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------
+static inline int ew_grid(long total_threads) {
+  long blocks = (total_threads + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
+                            float* lse2, int B, int H, int N, int head_dim, float scale, hipStream_t stream) {
+  if (head_dim != D) return OSUF_EUNSUPPORTED;
+  if (B <= 0 || H <= 0 || N <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || !al16(q) || !al16(k) || !al16(v) || !al16(o)) return OSUF_EINVAL;
+  AttnArgs a = {};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
+  a.o = o; a.ldo = ldo; a.o_is_f32 = o_dtype == OSUF_DT_F32; a.lse2 = lse2; a.B = B; a.H = H; a.N = N; a.scale = scale;
+  const int nvb = ((N + 31) / 32) * H;
+  hipLaunchKernelGGL(mqa_fwd_kernel, dim3((nvb + 7) / 8, B), dim3(512), 32768, stream, a);
+  return osuf_launch_status();
+}
+
+// delta: [B][H][N] fp32 scratch (written here).  dq: fp32 [B*N][lddq]; dk, dv: fp32 [B*N][lddk]
+extern "C" int osuf_mqa_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* o, long ldo, int o_dtype,
+                            const void* dout, long lddo, const float* lse2, float* delta, float* dq, long lddq, float* dk, float* dv,
+                            long lddk, int B, int H, int N, int head_dim, float scale, hipStream_t stream) {
+  if (head_dim != D) return OSUF_EUNSUPPORTED;
+  if (B <= 0 || H <= 0 || N <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8 || lddq % 4 || lddk % 4) return OSUF_EINVAL;
+  if (!al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(dout) || !al16(dq) || !al16(dk) || !al16(dv)) return OSUF_EINVAL;
+  const long tot = (long)B * N * H * 8;
+  if (o_dtype == OSUF_DT_F32) {
+    hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(ew_grid(tot)), dim3(256), 0, stream, (const bf16_t*)dout, lddo, (const float*)o, ldo, delta, B, H, N);
+  } else {
+    hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3(ew_grid(tot)), dim3(256), 0, stream, (const bf16_t*)dout, lddo, (const bf16_t*)o, ldo, delta, B, H, N);
+  }
+  AttnArgs a = {};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
+  a.lse2 = const_cast<float*>(lse2); a.dout = (const bf16_t*)dout; a.lddo = lddo; a.delta = delta;
+  a.dq = dq; a.lddq = lddq; a.dk = dk; a.dv = dv; a.lddk = lddk; a.B = B; a.H = H; a.N = N; a.scale = scale;
+  const int nvb = ((N + 31) / 32) * H;
+  hipLaunchKernelGGL(mqa_bwd_dq_kernel, dim3((nvb + 7) / 8, B), dim3(512), 32768, stream, a);
+  hipLaunchKernelGGL(mqa_bwd_dkv_kernel, dim3((N + 255) / 256, B), dim3(512), 2 * (4096 + 4096 + 256), stream, a);
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_rope_cast(int dtype, const void* in, long ld_in, void* out, long ld_out, const float* cosb, const float* sinb,
+                              int M, int N, int n_rot_heads, int n_heads_total, int head_dim, hipStream_t stream) {
+  if (head_dim != D) return OSUF_EUNSUPPORTED;
+  if (M <= 0 || N <= 0 || M % N || ld_in % 8 || ld_out % 8 || !al16(in) || !al16(out)) return OSUF_EINVAL;
+  const long tot = (long)M * n_heads_total * 4;
+  if (dtype == OSUF_DT_BF16) {
+    hipLaunchKernelGGL(rope_cast_kernel<bf16_t>, dim3(ew_grid(tot)), dim3(256), 0, stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, cosb, sinb, M, N, n_rot_heads, n_heads_total);
+  } else if (dtype == OSUF_DT_F32) {
+    hipLaunchKernelGGL(rope_cast_kernel<float>, dim3(ew_grid(tot)), dim3(256), 0, stream, (const float*)in, ld_in, (bf16_t*)out, ld_out, cosb, sinb, M, N, n_rot_heads, n_heads_total);
+  } else return OSUF_EUNSUPPORTED;
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_rope_bwd(int dtype, const float* in, long ld_in, void* out, long ld_out, const float* cosb, const float* sinb,
+                             int M, int N, int n_rot_heads, int n_heads_total, int head_dim, hipStream_t stream) {
+  if (head_dim != D) return OSUF_EUNSUPPORTED;
+  if (M <= 0 || N <= 0 || M % N || ld_in % 8 || ld_out % 8 || !al16(in) || !al16(out)) return OSUF_EINVAL;
+  const long tot = (long)M * n_heads_total * 4;
+  if (dtype == OSUF_DT_BF16) {
+    hipLaunchKernelGGL(rope_bwd_kernel<bf16_t>, dim3(ew_grid(tot)), dim3(256), 0, stream, in, ld_in, (bf16_t*)out, ld_out, cosb, sinb, M, N, n_rot_heads, n_heads_total);
+  } else if (dtype == OSUF_DT_F32) {
+    hipLaunchKernelGGL(rope_bwd_kernel<float>, dim3(ew_grid(tot)), dim3(256), 0, stream, in, ld_in, (float*)out, ld_out, cosb, sinb, M, N, n_rot_heads, n_heads_total);
+  } else return OSUF_EUNSUPPORTED;
+  return osuf_launch_status();
+}

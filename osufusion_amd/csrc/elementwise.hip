@@ -1,0 +1,287 @@
+// Layout conversion, diffusion-scheduler algebra and optimizer kernels (HBM-bound, 16 B per lane), gfx950.
+#include "common.hpp"
+
+static inline int ew_grid(long total_threads) {
+  long blocks = (total_threads + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+#define GRID_STRIDE(idx, total) \
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (total); idx += (long)gridDim.x * blockDim.x)
+
+// (B, C, L) fp32 channel-major  ->  channels-last rows [B*L][ld] of T, optionally im2col over KT taps:
+//   out[b*L + n][t*C + ci] = in[b][ci][n + t - KT/2]   (zero outside [0, L)); columns KT*C .. width-1 are zeroed.
+// KT = 1 is a plain transpose (audio stem input); KT = 15 builds the 6-channel x stem's GEMM operand so the
+// three CrossEmbed convs (k = 3, 7, 15; unet.py:42-58) become ONE K = 96 GEMM.
+template <typename T>
+__global__ __launch_bounds__(256) void ncl_to_rows_kernel(const float* in, T* out, long ld, int width, int B, int C, int L, int KT) {
+  const int chunks = width >> 3;
+  const long total = (long)B * L * chunks;
+  GRID_STRIDE(idx, total) {
+    // n fastest so the strided reads of `in` coalesce across lanes
+    const int n = (int)(idx % L);
+    const long r = idx / L;
+    const int ch = (int)(r % chunks);
+    const int b = (int)(r / chunks);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int col = ch * 8 + e;
+      const int t = col / C, ci = col - t * C;
+      const int src = n + t - KT / 2;
+      v[e] = (t < KT && src >= 0 && src < L) ? in[((long)b * C + ci) * L + src] : 0.f;
+    }
+    store8(out + ((long)b * L + n) * ld + ch * 8, v);
+  }
+}
+
+// rows [B*L][ld] of T (first C columns)  ->  (B, C, L) fp32
+template <typename T>
+__global__ __launch_bounds__(256) void rows_to_ncl_kernel(const T* in, long ld, float* out, int B, int C, int L) {
+  const long total = (long)B * C * L;
+  GRID_STRIDE(idx, total) {
+    const int n = (int)(idx % L);
+    const long r = idx / L;
+    const int ci = (int)(r % C);
+    const int b = (int)(r / C);
+    out[idx] = ElemTraits<T>::load(in + ((long)b * L + n) * ld + ci);
+  }
+}
+
+// strided 2-D copy with optional dtype change: dst[m][0..cols) = src[m][0..cols)   (cat / slice / cast)
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void copy2d_kernel(const TS* src, long lds_, TD* dst, long ldd, int M, int cols) {
+  const int chunks = cols >> 3;
+  const long total = (long)M * chunks;
+  GRID_STRIDE(idx, total) {
+    const long m = idx / chunks;
+    const int c = (int)(idx - m * chunks) * 8;
+    float v[8];
+    load8(src + m * lds_ + c, v);
+    store8(dst + m * ldd + c, v);
+  }
+}
+
+// dst[m][c] = a[m][c] + b[m][c]
+template <typename T>
+__global__ __launch_bounds__(256) void add2d_kernel(const T* a, long lda, const T* b, long ldb, T* dst, long ldd, int M, int cols) {
+  const int chunks = cols >> 3;
+  const long total = (long)M * chunks;
+  GRID_STRIDE(idx, total) {
+    const long m = idx / chunks;
+    const int c = (int)(idx - m * chunks) * 8;
+    float x[8], y[8];
+    load8(a + m * lda + c, x);
+    load8(b + m * ldb + c, y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] += y[e];
+    store8(dst + m * ldd + c, x);
+  }
+}
+
+// ---- DDPM / DDIM algebra on (B, D, L) fp32 tensors; per-sample coefficients in device arrays -------------
+// out = ca[b] * x + cb[b] * y                      add_noise: ca = sqrt(acp_t), cb = sqrt(1 - acp_t)
+__global__ __launch_bounds__(256) void axpby_rows_kernel(const float* x, const float* y, const float* ca, const float* cb, float* out,
+                                                         long per_sample, long total) {
+  GRID_STRIDE(idx, total) {
+    const long b = idx / per_sample;
+    out[idx] = ca[b] * x[idx] + cb[b] * y[idx];
+  }
+}
+
+// DDIM step (eta = 0, epsilon prediction, clip_sample): coef[b] = {sqrt(1-a_t), sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev)}
+// eps = null + (cond - null) * cond_scale when `null` is given (classifier-free guidance, unet.py:458-465)
+__global__ __launch_bounds__(256) void ddim_step_kernel(const float* x, const float* cond, const float* nullp, float cond_scale,
+                                                        const float* coef, float* out, long per_sample, long total) {
+  GRID_STRIDE(idx, total) {
+    const long b = idx / per_sample;
+    float eps = cond[idx];
+    if (nullp) { const float nu = nullp[idx]; eps = nu + (eps - nu) * cond_scale; }
+    const float* c = coef + 4 * b;
+    float x0 = (x[idx] - c[0] * eps) / c[1];
+    x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    out[idx] = c[2] * x0 + c[3] * eps;
+  }
+}
+
+// masked MSE: loss_sum += sum w*(pred-target)^2 (double), grad = 2*w*(pred-target)  (scaled by 1/count later)
+__global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float* target, const int* orig_len, float* grad, double* loss_sum,
+                                                  int Dch, int L, long total) {
+  float local = 0.f;
+  GRID_STRIDE(idx, total) {
+    const int n = (int)(idx % L);
+    const long b = idx / ((long)Dch * L);
+    const float w = (!orig_len || n < orig_len[b]) ? 1.f : 0.f;
+    const float d = pred[idx] - target[idx];
+    local += w * d * d;
+    if (grad) grad[idx] = 2.f * w * d;
+  }
+  local = group_sum<64>(local);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) atomic_add_f64(loss_sum, (double)(red[0] + red[1] + red[2] + red[3]));
+}
+
+// ---- optimizer --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long n, double* out) {
+  float local = 0.f;
+  const long n4 = n >> 2;
+  GRID_STRIDE(i, n4) {
+    f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+    local += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { float v = g[(n4 << 2) + threadIdx.x]; local += v * v; }
+  local = group_sum<64>(local);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) atomic_add_f64(out, (double)(red[0] + red[1] + red[2] + red[3]));
+}
+
+// torch.optim.AdamW semantics (decoupled decay), one launch over the flat parameter buffer.
+// gscale (device scalar, may be null) multiplies the gradient: 1/world or a clip coefficient, no host sync.
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                                                    float eps, float wd, float inv_bc1, float inv_sqrt_bc2, const float* gscale) {
+  const float gs = gscale ? *gscale : 1.f;
+  const long n4 = n >> 2;
+  GRID_STRIDE(i, n4) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ge = gv[e] * gs;
+      pv[e] *= 1.f - lr * wd;
+      mv[e] = beta1 * mv[e] + (1.f - beta1) * ge;
+      vv[e] = beta2 * vv[e] + (1.f - beta2) * ge * ge;
+      const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
+      pv[e] -= lr * inv_bc1 * mv[e] / denom;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (n4 << 2) + threadIdx.x;
+    const float ge = g[i] * gs;
+    float pe = p[i] * (1.f - lr * wd);
+    const float me = beta1 * m[i] + (1.f - beta1) * ge;
+    const float ve = beta2 * v[i] + (1.f - beta2) * ge * ge;
+    pe -= lr * inv_bc1 * me / (sqrtf(ve) * inv_sqrt_bc2 + eps);
+    p[i] = pe; m[i] = me; v[i] = ve;
+  }
+}
+
+// clip coefficient on device: coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)) * base   (torch clip_grad_norm_ semantics)
+__global__ void clip_coef_kernel(const double* sumsq, float max_norm, float base, float* coef, float* total_norm) {
+  const float tn = (float)sqrt(*sumsq);
+  if (total_norm) *total_norm = tn;
+  float c = base;
+  if (max_norm > 0.f) c *= fminf(1.f, max_norm / (tn + 1e-6f));
+  *coef = c;
+}
+
+// fp32 master -> bf16 copy of a flat range (weight packing for linear layers)
+__global__ __launch_bounds__(256) void cast_flat_kernel(const float* src, bf16_t* dst, long n) {
+  const long n8 = n >> 3;
+  GRID_STRIDE(i, n8) {
+    float v[8];
+    load8(src + i * 8, v);
+    store8(dst + i * 8, v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) { const long i = (n8 << 3) + threadIdx.x; dst[i] = f32_to_bf16(src[i]); }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int osuf_ncl_to_rows(int dtype, const float* in, void* out, long ld, int width, int B, int C, int L, int KT, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || L <= 0 || KT <= 0 || width % 8 || ld % 8 || width < C * KT || width > ld || !al16(out)) return OSUF_EINVAL;
+  const long tot = (long)B * L * (width / 8);
+  if (dtype == OSUF_DT_BF16) hipLaunchKernelGGL(ncl_to_rows_kernel<bf16_t>, dim3(ew_grid(tot)), dim3(256), 0, stream, in, (bf16_t*)out, ld, width, B, C, L, KT);
+  else if (dtype == OSUF_DT_F32) hipLaunchKernelGGL(ncl_to_rows_kernel<float>, dim3(ew_grid(tot)), dim3(256), 0, stream, in, (float*)out, ld, width, B, C, L, KT);
+  else return OSUF_EUNSUPPORTED;
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_rows_to_ncl(int dtype, const void* in, long ld, float* out, int B, int C, int L, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || L <= 0 || ld < C) return OSUF_EINVAL;
+  const long tot = (long)B * C * L;
+  if (dtype == OSUF_DT_BF16) hipLaunchKernelGGL(rows_to_ncl_kernel<bf16_t>, dim3(ew_grid(tot)), dim3(256), 0, stream, (const bf16_t*)in, ld, out, B, C, L);
+  else if (dtype == OSUF_DT_F32) hipLaunchKernelGGL(rows_to_ncl_kernel<float>, dim3(ew_grid(tot)), dim3(256), 0, stream, (const float*)in, ld, out, B, C, L);
+  else return OSUF_EUNSUPPORTED;
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_copy2d(int src_dtype, const void* src, long lds_, int dst_dtype, void* dst, long ldd, int M, int cols, hipStream_t stream) {
+  if (M <= 0 || cols <= 0 || cols % 8 || lds_ % 8 || ldd % 8 || !al16(src) || !al16(dst)) return OSUF_EINVAL;
+  const long tot = (long)M * (cols / 8);
+  const dim3 g(ew_grid(tot)), b(256);
+  if (src_dtype == OSUF_DT_BF16 && dst_dtype == OSUF_DT_BF16) hipLaunchKernelGGL((copy2d_kernel<bf16_t, bf16_t>), g, b, 0, stream, (const bf16_t*)src, lds_, (bf16_t*)dst, ldd, M, cols);
+  else if (src_dtype == OSUF_DT_F32 && dst_dtype == OSUF_DT_F32) hipLaunchKernelGGL((copy2d_kernel<float, float>), g, b, 0, stream, (const float*)src, lds_, (float*)dst, ldd, M, cols);
+  else if (src_dtype == OSUF_DT_F32 && dst_dtype == OSUF_DT_BF16) hipLaunchKernelGGL((copy2d_kernel<float, bf16_t>), g, b, 0, stream, (const float*)src, lds_, (bf16_t*)dst, ldd, M, cols);
+  else if (src_dtype == OSUF_DT_BF16 && dst_dtype == OSUF_DT_F32) hipLaunchKernelGGL((copy2d_kernel<bf16_t, float>), g, b, 0, stream, (const bf16_t*)src, lds_, (float*)dst, ldd, M, cols);
+  else return OSUF_EUNSUPPORTED;
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_add2d(int dtype, const void* a, long lda, const void* b, long ldb, void* dst, long ldd, int M, int cols, hipStream_t stream) {
+  if (M <= 0 || cols <= 0 || cols % 8 || lda % 8 || ldb % 8 || ldd % 8) return OSUF_EINVAL;
+  const long tot = (long)M * (cols / 8);
+  if (dtype == OSUF_DT_BF16) hipLaunchKernelGGL(add2d_kernel<bf16_t>, dim3(ew_grid(tot)), dim3(256), 0, stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)dst, ldd, M, cols);
+  else if (dtype == OSUF_DT_F32) hipLaunchKernelGGL(add2d_kernel<float>, dim3(ew_grid(tot)), dim3(256), 0, stream, (const float*)a, lda, (const float*)b, ldb, (float*)dst, ldd, M, cols);
+  else return OSUF_EUNSUPPORTED;
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_axpby_rows(const float* x, const float* y, const float* ca, const float* cb, float* out, int B, long per_sample, hipStream_t stream) {
+  if (B <= 0 || per_sample <= 0) return OSUF_EINVAL;
+  const long tot = (long)B * per_sample;
+  hipLaunchKernelGGL(axpby_rows_kernel, dim3(ew_grid(tot)), dim3(256), 0, stream, x, y, ca, cb, out, per_sample, tot);
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_ddim_step(const float* x, const float* cond, const float* nullp, float cond_scale, const float* coef, float* out,
+                              int B, long per_sample, hipStream_t stream) {
+  if (B <= 0 || per_sample <= 0) return OSUF_EINVAL;
+  const long tot = (long)B * per_sample;
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(ew_grid(tot)), dim3(256), 0, stream, x, cond, nullp, cond_scale, coef, out, per_sample, tot);
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_mse(const float* pred, const float* target, const int* orig_len, float* grad, double* loss_sum, int B, int Dch, int L,
+                        hipStream_t stream) {
+  if (B <= 0 || Dch <= 0 || L <= 0) return OSUF_EINVAL;
+  const long tot = (long)B * Dch * L;
+  hipLaunchKernelGGL(mse_kernel, dim3(ew_grid(tot)), dim3(256), 0, stream, pred, target, orig_len, grad, loss_sum, Dch, L, tot);
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_sqnorm(const float* g, long n, double* out, hipStream_t stream) {
+  if (n <= 0 || !al16(g)) return OSUF_EINVAL;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, stream, g, n, out);
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
+                          int step, const float* gscale, hipStream_t stream) {
+  if (n <= 0 || step <= 0 || !al16(p) || !al16(g) || !al16(m) || !al16(v)) return OSUF_EINVAL;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps, wd,
+                     (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), gscale);
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_clip_coef(const double* sumsq, float max_norm, float base, float* coef, float* total_norm, hipStream_t stream) {
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, sumsq, max_norm, base, coef, total_norm);
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t stream) {
+  if (n <= 0 || !al16(src) || !al16(dst)) return OSUF_EINVAL;
+  hipLaunchKernelGGL(cast_flat_kernel, dim3(ew_grid(n / 8 + 1)), dim3(256), 0, stream, src, (bf16_t*)dst, n);
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_version(void) { return 1; }

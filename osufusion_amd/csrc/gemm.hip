@@ -1,0 +1,509 @@
+// Tap-aware GEMMs for the conv1d / linear layers of the denoiser, gfx950 only.
+//
+//   gemm_nt : C[m][n] = epi( sum_t sum_k A[rowmap(m,t)][k] * W[t][n][k] )       (fwd conv / linear / dgrad)
+//   gemm_tn : dW[t][n1][n2] += sum_m dY[m][n1] * X[rowmap(m,t)][n2]             (wgrad, split over m, fp32 atomics)
+//
+// Activations are channels-last ([B*L][C], C contiguous) so a k-tap conv1d is k accumulating GEMMs whose
+// A rows are shifted by the tap; both MFMA operands are K-contiguous (weights are pre-packed [tap][N][K]).
+// bf16 storage -> v_mfma_f32_32x32x16_bf16; f32 storage -> v_mfma_f32_32x32x2_f32 (exact f32 fmaf chain).
+// Block tile 128x128, 4 waves (2x2), wave tile 64x64 = 2x2 MFMA tiles; K-step = 128 bytes of K per row.
+// Global -> registers -> LDS double buffering (one barrier per K-step), XOR-swizzled 16-B chunks so the
+// ds_read_b128 fragment reads are conflict-free; epilogue goes through LDS so HBM stores are full rows.
+#include "common.hpp"
+
+struct RowMap {
+  int Lin, Lout, stride, pad, mode;
+};
+// mode 0: src = i*stride + t - pad, zero outside [0, Lin)
+// mode 1: as 0, but src == Lin reflects to Lin-2            (Downsample: F.pad(x,(0,1),"reflect"), unet.py:84-87)
+// mode 2: u = i*stride + t - pad over the nearest-x2 upsampled input, zero outside [0, 2*Lin), src = u>>1
+//                                                           (Upsample fwd, unet.py:66-69; with stride=2 its dgrad)
+// mode 3: dgrad of mode 1 (stride 2, k3): t<3: e = i - t, valid iff e even and 0 <= e/2 < Lin, src = e/2;
+//         t==3: valid iff i == Lout-2, src = Lin-1          (the reflected column's contribution)
+__device__ __forceinline__ int map_row(const RowMap& rm, int i, int t) {
+  if (rm.mode == 3) {
+    if (t == 3) return (i == rm.Lout - 2) ? rm.Lin - 1 : -1;
+    int e = i - t;
+    if (e < 0 || (e & 1)) return -1;
+    e >>= 1;
+    return e < rm.Lin ? e : -1;
+  }
+  int s = i * rm.stride + t - rm.pad;
+  if (rm.mode == 2) {
+    if (s < 0 || s >= 2 * rm.Lin) return -1;
+    return s >> 1;
+  }
+  if (rm.mode == 1 && s == rm.Lin) s = rm.Lin - 2;
+  return (s >= 0 && s < rm.Lin) ? s : -1;
+}
+
+struct GemmArgs {
+  const void* A; const void* W; void* C; void* C2; const void* R; const void* U;
+  const float* bias; const float* rscale; double* stats;
+  long lda, ldw, tapstride, ldc, ldc2, ldr, ldu;
+  int M, N, K, taps;
+  RowMap rm;
+  int act;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> { static constexpr int BK = 64; };
+template <> struct Mma<float> { static constexpr int BK = 32; };
+
+static constexpr int kTile = 128;
+static constexpr int kStageBytes = 2 * kTile * 128;   // A tile + B tile, 128 B of K per row
+
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BK = Mma<T>::BK;
+  constexpr int EPC = ElemTraits<T>::kPer16B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_n = (g.N + kTile - 1) / kTile;
+  const int m0 = (blockIdx.x / tiles_n) * kTile, n0 = (blockIdx.x % tiles_n) * kTile;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+
+  // staging assignment: chunk column c (16 B of K), rows r0 + 32*i
+  const int c = tid & 7, r0 = tid >> 3;
+  int a_base[4], a_pos[4];
+  bool b_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + r0 + 32 * i;
+    if (m < g.M) { int b = m / g.rm.Lout; a_base[i] = b * g.rm.Lin; a_pos[i] = m - b * g.rm.Lout; }
+    else { a_base[i] = 0; a_pos[i] = -1; }
+    b_ok[i] = (n0 + r0 + 32 * i) < g.N;
+  }
+  const int ksteps = (g.K + BK - 1) / BK;
+  const int nsteps = g.taps * ksteps;
+
+  u32x4 ra[4], rb[4];
+  auto load_regs = [&](int step) {
+    const int t = step / ksteps, kb = step - t * ksteps;
+    const int k = kb * BK + c * EPC;
+    const bool kok = k < g.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 z = {0u, 0u, 0u, 0u};
+      ra[i] = z; rb[i] = z;
+      if (kok && a_pos[i] >= 0) {
+        int s = map_row(g.rm, a_pos[i], t);
+        if (s >= 0) ra[i] = *reinterpret_cast<const u32x4*>(A + (long)(a_base[i] + s) * g.lda + k);
+      }
+      if (kok && b_ok[i])
+        rb[i] = *reinterpret_cast<const u32x4*>(W + (long)t * g.tapstride + (long)(n0 + r0 + 32 * i) * g.ldw + k);
+    }
+  };
+  auto store_lds = [&](int buf) {
+    char* sa = smem + buf * kStageBytes;
+    char* sb = sa + kTile * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int off = swz_off(r0 + 32 * i, c);
+      *reinterpret_cast<u32x4*>(sa + off) = ra[i];
+      *reinterpret_cast<u32x4*>(sb + off) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_regs(0);
+  store_lds(0);
+  __syncthreads();
+  const int lr = lane & 31, lh = lane >> 5;
+  for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
+    if (step + 1 < nsteps) load_regs(step + 1);
+    const char* sa = smem + buf * kStageBytes;
+    const char* sb = sa + kTile * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *reinterpret_cast<const u32x4*>(sa + swz_off(wr * 64 + i * 32 + lr, 2 * ks + lh));
+        fb[i] = *reinterpret_cast<const u32x4*>(sb + swz_off(wc * 64 + i * 32 + lr, 2 * ks + lh));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (sizeof(T) == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                 __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+          } else {
+            f32x4 va = __builtin_bit_cast(f32x4, fa[i]), vb = __builtin_bit_cast(f32x4, fb[j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e], vb[e], acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    if (step + 1 < nsteps) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS (fp32 [128][128]) -> coalesced row stores -------------------------
+  float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        cs[row * kTile + wc * 64 + j * 32 + lr] = acc[i][j][r];
+      }
+  // per-sample (sum, sumsq) slots of this tile live in the 512 B behind the C tile (all LDS is dynamic: G17)
+  float* sstat = reinterpret_cast<float*>(smem + 2 * kStageBytes);
+  int sb0 = 0;
+  if (g.stats) {
+    sb0 = m0 / g.rm.Lout;
+    if (tid < 2 * 34) sstat[tid] = 0.f;
+  }
+  __syncthreads();
+
+  T* C = reinterpret_cast<T*>(g.C);
+  T* C2 = reinterpret_cast<T*>(g.C2);
+  const T* R = reinterpret_cast<const T*>(g.R);
+  const T* U = reinterpret_cast<const T*>(g.U);
+  const int col4 = (tid & 31) * 4;
+  const int n = n0 + col4;
+  const bool nok = n < g.N;        // N % 4 == 0 is required by the host wrapper
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias && nok) { f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n); bias4[0] = b[0]; bias4[1] = b[1]; bias4[2] = b[2]; bias4[3] = b[3]; }
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 8 + (tid >> 5);
+    const int m = m0 + row;
+    float s1 = 0.f, s2 = 0.f;
+    int bidx = 0;
+    if (m < g.M && nok) {
+      f32x4 a4 = *reinterpret_cast<const f32x4*>(cs + row * kTile + col4);
+      float v[4] = {a4[0] + bias4[0], a4[1] + bias4[1], a4[2] + bias4[2], a4[3] + bias4[3]};
+      if (C2) store4(C2 + (long)m * g.ldc2 + n, v);
+      if (g.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+      } else if (g.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = sigmoid_f(v[e]);
+      }
+      if (U) {
+        float u[4];
+        load4(U + (long)m * g.ldu + n, u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= silu_grad_f(u[e]);
+      }
+      bidx = m / g.rm.Lout;
+      if (R) {
+        float rr[4];
+        load4(R + (long)m * g.ldr + n, rr);
+        if (g.rscale) {
+          f32x4 sc = *reinterpret_cast<const f32x4*>(g.rscale + (long)bidx * g.N + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += rr[e] * sc[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += rr[e];
+        }
+      }
+      store4(C + (long)m * g.ldc + n, v);
+      if (g.stats) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float q = ElemTraits<T>::rnd(v[e]); s1 += q; s2 += q * q; }
+      }
+    }
+    if (g.stats) {                       // uniform branch; one row per 32-lane half
+      s1 = group_sum<32>(s1);
+      s2 = group_sum<32>(s2);
+      if ((tid & 31) == 0 && m < g.M) {
+        int slot = bidx - sb0;
+        if (slot < 34) { atomicAdd(&sstat[2 * slot], s1); atomicAdd(&sstat[2 * slot + 1], s2); }
+        else { atomic_add_f64(g.stats + 2 * (long)bidx, (double)s1); atomic_add_f64(g.stats + 2 * (long)bidx + 1, (double)s2); }
+      }
+    }
+  }
+  if (g.stats) {
+    __syncthreads();
+    if (tid < 2 * 34) {
+      int slot = tid >> 1;
+      long b = sb0 + slot;
+      float v = sstat[tid];
+      if (v != 0.f && b * g.rm.Lout < g.M) atomic_add_f64(g.stats + 2 * b + (tid & 1), (double)v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// wgrad: dW[t][n1][n2] += sum_m dY[m][n1] * X[rowmap(m,t)][n2]
+// ---------------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const void* dY; const void* X; float* dW;
+  long ldy, ldx, ldw, tapstride;
+  int M, N1, N2, taps;
+  RowMap rm;
+  int rows_per_split;
+};
+
+// bf16 tile: [64 rows][128 cols] (256 B/row), byte-in-row ^= (row&3)<<6 -> ds_read_b64_tr_b16 conflict-free
+// f32  tile: [32 rows][128 cols] (512 B/row), plain ds_read_b32 (lanes = consecutive columns)
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool kBF = sizeof(T) == 2;
+  constexpr int BKM = kBF ? 64 : 32;                // rows of m per step
+  constexpr int EPC = ElemTraits<T>::kPer16B;
+  constexpr int CPR = kTile / EPC;                  // 16-B chunks per tile row: 16 (bf16) / 32 (f32)
+  constexpr int ROWB = kTile * (int)sizeof(T);      // bytes per tile row
+  constexpr int TILEB = BKM * ROWB;                 // 16 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_n2 = (g.N2 + kTile - 1) / kTile;
+  const int n1_0 = (blockIdx.x / tiles_n2) * kTile, n2_0 = (blockIdx.x % tiles_n2) * kTile;
+  const int t = blockIdx.y;
+  const int m_begin = blockIdx.z * g.rows_per_split;
+  const int m_end = min(g.M, m_begin + g.rows_per_split);
+  if (m_begin >= m_end) return;
+  const T* dY = reinterpret_cast<const T*>(g.dY);
+  const T* X = reinterpret_cast<const T*>(g.X);
+
+  const int c = tid % CPR, r0 = tid / CPR;          // rows r0 + (256/CPR)*i
+  constexpr int RSTEP = 256 / CPR;                  // 16 (bf16) / 8 (f32)
+  const bool y_ok = (n1_0 + c * EPC) < g.N1, x_ok = (n2_0 + c * EPC) < g.N2;
+
+  u32x4 ry[4], rx[4];
+  auto load_regs = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 z = {0u, 0u, 0u, 0u};
+      ry[i] = z; rx[i] = z;
+      int m = mb + r0 + RSTEP * i;
+      if (m < m_end) {
+        if (y_ok) ry[i] = *reinterpret_cast<const u32x4*>(dY + (long)m * g.ldy + n1_0 + c * EPC);
+        if (x_ok) {
+          int b = m / g.rm.Lout;
+          int s = map_row(g.rm, m - b * g.rm.Lout, t);
+          if (s >= 0) rx[i] = *reinterpret_cast<const u32x4*>(X + (long)(b * g.rm.Lin + s) * g.ldx + n2_0 + c * EPC);
+        }
+      }
+    }
+  };
+  auto store_lds = [&](int buf) {
+    char* sy = smem + buf * 2 * TILEB;
+    char* sx = sy + TILEB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int row = r0 + RSTEP * i;
+      int off = row * ROWB + (kBF ? ((c * 16) ^ ((row & 3) << 6)) : c * 16);
+      *reinterpret_cast<u32x4*>(sy + off) = ry[i];
+      *reinterpret_cast<u32x4*>(sx + off) = rx[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  // transposed-read lane roles (ds_read_b64_tr_b16 works per 16-lane group; see cdna_hip_programming.md T10)
+  const int ip = lane & 15, cb = ((lane >> 4) & 1) * 16, tq = ip >> 2, tp = ip & 3;
+
+  load_regs(m_begin);
+  store_lds(0);
+  __syncthreads();
+  int buf = 0;
+  for (int mb = m_begin; mb < m_end; mb += BKM, buf ^= 1) {
+    const bool more = mb + BKM < m_end;
+    if (more) load_regs(mb + BKM);
+    const char* sy = smem + buf * 2 * TILEB;
+    const char* sx = sy + TILEB;
+    if constexpr (kBF) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          s16x4 lo[2], hi[2];
+#pragma unroll
+          for (int q4 = 0; q4 < 2; ++q4) {
+            int row = 16 * ks + 8 * lh + 4 * q4 + tq;
+            int sw = (row & 3) << 6;
+            int cola = (wr * 64 + i * 32 + cb + 4 * tp) * 2;
+            int colb = (wc * 64 + i * 32 + cb + 4 * tp) * 2;
+            lo[q4] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(sy + row * ROWB + (cola ^ sw)));
+            hi[q4] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(sx + row * ROWB + (colb ^ sw)));
+          }
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          s16x8 va = {lo[0][0], lo[0][1], lo[0][2], lo[0][3], lo[1][0], lo[1][1], lo[1][2], lo[1][3]};
+          s16x8 vb = {hi[0][0], hi[0][1], hi[0][2], hi[0][3], hi[1][0], hi[1][1], hi[1][2], hi[1][3]};
+          fa[i] = __builtin_bit_cast(bf16x8, va);
+          fb[i] = __builtin_bit_cast(bf16x8, vb);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int ks = 0; ks < 16; ++ks) {
+        const int row = 2 * ks + lh;
+        float fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[i] = *reinterpret_cast<const float*>(sy + row * ROWB + (wr * 64 + i * 32 + lr) * 4);
+          fb[i] = *reinterpret_cast<const float*>(sx + row * ROWB + (wc * 64 + i * 32 + lr) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* dW = g.dW + (long)t * g.tapstride;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int n2 = n2_0 + wc * 64 + j * 32 + lr;
+      if (n2 < g.N2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int n1 = n1_0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (n1 < g.N1) atomic_add_f32(dW + (long)n1 * g.ldw + n2, acc[i][j][r]);
+        }
+      }
+    }
+}
+
+// column sums: out[n] += sum_m Y[m][n]   (bias gradients)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* Y, long ldy, int M, int N, float* out, int rows_per_block) {
+  // block: 32 column-chunks (8 elems) x 8 row lanes
+  const int cchunk = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int rl = threadIdx.x >> 5;
+  const int n = cchunk * 8;
+  const int m_begin = blockIdx.y * rows_per_block;
+  const int m_end = min(M, m_begin + rows_per_block);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (n < N) {
+    for (int m = m_begin + rl; m < m_end; m += 8) {
+      float v[8];
+      load8(Y + (long)m * ldy + n, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+  }
+  __shared__ float red[8][32 * 8 + 1];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][(threadIdx.x & 31) * 8 + e] = acc[e];
+  __syncthreads();
+  const int col = threadIdx.x;                       // 256 columns of this block
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) s += red[r][col];
+  const int nn = blockIdx.x * 256 + col;
+  if (nn < N) atomic_add_f32(out + nn, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, long ldw, long tapstride,
+                            void* C, long ldc, void* C2, long ldc2, const void* R, long ldr, const void* U, long ldu,
+                            const float* bias, const float* rscale, double* stats,
+                            int M, int N, int K, int taps, int Lin, int Lout, int stride, int pad, int mode, int act,
+                            hipStream_t stream) {
+  const int epc = dtype == OSUF_DT_BF16 ? 8 : 4;
+  if (dtype != OSUF_DT_BF16 && dtype != OSUF_DT_F32) return OSUF_EUNSUPPORTED;
+  if (M <= 0 || N <= 0 || K <= 0 || taps <= 0 || Lout <= 0 || Lin <= 0) return OSUF_EINVAL;
+  if (M % Lout != 0) return OSUF_EINVAL;
+  if (K % epc || lda % epc || ldw % epc || tapstride % epc || N % 4 || ldc % 4) return OSUF_EINVAL;
+  if ((C2 && ldc2 % 4) || (R && ldr % 4) || (U && ldu % 4)) return OSUF_EINVAL;
+  if (!aligned16(A) || !aligned16(W) || !aligned16(C) || (bias && !aligned16(bias)) || (rscale && !aligned16(rscale))) return OSUF_EINVAL;
+  if ((long)(M / Lout) * Lin >= (1L << 31)) return OSUF_EINVAL;
+  GemmArgs g;
+  g.A = A; g.W = W; g.C = C; g.C2 = C2; g.R = R; g.U = U; g.bias = bias; g.rscale = rscale; g.stats = stats;
+  g.lda = lda; g.ldw = ldw; g.tapstride = tapstride; g.ldc = ldc; g.ldc2 = ldc2; g.ldr = ldr; g.ldu = ldu;
+  g.M = M; g.N = N; g.K = K; g.taps = taps;
+  g.rm = RowMap{Lin, Lout, stride, pad, mode};
+  g.act = act;
+  const int grid = ((M + kTile - 1) / kTile) * ((N + kTile - 1) / kTile);
+  const int lds = 2 * kStageBytes + 512;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  if (dtype == OSUF_DT_BF16) {
+    hipLaunchKernelGGL(gemm_nt_kernel<bf16_t>, dim3(grid), dim3(256), lds, stream, g);
+  } else {
+    hipLaunchKernelGGL(gemm_nt_kernel<float>, dim3(grid), dim3(256), lds, stream, g);
+  }
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, long tapstride,
+                            int M, int N1, int N2, int taps, int Lin, int Lout, int stride, int pad, int mode,
+                            int splits, hipStream_t stream) {
+  const int epc = dtype == OSUF_DT_BF16 ? 8 : 4;
+  if (dtype != OSUF_DT_BF16 && dtype != OSUF_DT_F32) return OSUF_EUNSUPPORTED;
+  if (M <= 0 || N1 <= 0 || N2 <= 0 || taps <= 0 || Lout <= 0 || Lin <= 0 || M % Lout) return OSUF_EINVAL;
+  if (N1 % epc || N2 % epc || ldy % epc || ldx % epc) return OSUF_EINVAL;
+  if (!aligned16(dY) || !aligned16(X)) return OSUF_EINVAL;
+  const int bkm = dtype == OSUF_DT_BF16 ? 64 : 32;
+  const int tiles = ((N1 + kTile - 1) / kTile) * ((N2 + kTile - 1) / kTile);
+  if (splits <= 0) {                                  // aim at ~3 workgroups per CU
+    splits = (768 + tiles * taps - 1) / (tiles * taps);
+  }
+  int rows = (M + splits - 1) / splits;
+  rows = ((rows + bkm - 1) / bkm) * bkm;
+  splits = (M + rows - 1) / rows;
+  WgradArgs g;
+  g.dY = dY; g.X = X; g.dW = dW; g.ldy = ldy; g.ldx = ldx; g.ldw = ldw; g.tapstride = tapstride;
+  g.M = M; g.N1 = N1; g.N2 = N2; g.taps = taps; g.rm = RowMap{Lin, Lout, stride, pad, mode};
+  g.rows_per_split = rows;
+  const int lds = 4 * 16384;
+  if (dtype == OSUF_DT_BF16) {
+    hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(tiles, taps, splits), dim3(256), lds, stream, g);
+  } else {
+    hipLaunchKernelGGL(gemm_tn_kernel<float>, dim3(tiles, taps, splits), dim3(256), lds, stream, g);
+  }
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_colsum(int dtype, const void* Y, long ldy, int M, int N, float* out, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || N % 8 || ldy % 8 || !aligned16(Y)) return OSUF_EINVAL;
+  const int rows_per_block = 512;
+  dim3 grid((N + 255) / 256, (M + rows_per_block - 1) / rows_per_block);
+  if (dtype == OSUF_DT_BF16) {
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)Y, ldy, M, N, out, rows_per_block);
+  } else if (dtype == OSUF_DT_F32) {
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, stream, (const float*)Y, ldy, M, N, out, rows_per_block);
+  } else {
+    return OSUF_EUNSUPPORTED;
+  }
+  return osuf_launch_status();
+}

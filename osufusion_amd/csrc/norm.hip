@@ -1,0 +1,603 @@
+// HBM-bound normalisation / gating kernels (channels-last [B*L][C] activations), gfx950.
+//   GroupNorm(1,C) + FiLM + SiLU     residual.py:62-88   (stats come from the conv GEMM epilogue)
+//   LayerNorm(C)                      unet.py:117,127
+//   GlobalContext pooling + gate      residual.py:14-37,135
+// Two skeletons: "column reduce" (a workgroup owns a row chunk of ONE sample, threads own 8-channel
+// chunks, partials go out as fp32 atomics to [B][C]) and "row-wise" (G lanes of a wave own one row,
+// wave64 xor-shuffle reductions).  All loads/stores are 16 B per lane.
+#include "common.hpp"
+
+static constexpr float kEps = 1e-5f;
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(1, C)
+// ------------------------------------------------------------------------------------------------
+__global__ void gn_finalize_kernel(const double* stats, float* mr, int B, double inv_count) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double mean = stats[2 * b] * inv_count;
+  double var = stats[2 * b + 1] * inv_count - mean * mean;      // biased variance (torch semantics)
+  if (var < 0.0) var = 0.0;
+  mr[2 * b] = (float)mean;
+  mr[2 * b + 1] = (float)(1.0 / sqrt(var + (double)kEps));
+}
+
+// h = silu( ((y-mean)*rstd*gamma + beta) * (1+scale) + shift );  ss = [B][2C] (scale | shift) or null
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const T* y, long ldy, T* h, long ldh, const float* mr,
+                                                           const float* gamma, const float* beta, const float* ss,
+                                                           int M, int C, int L) {
+  const int chunks = C >> 3;
+  const long total = (long)M * chunks;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(idx / chunks), c = (int)(idx - (long)m * chunks) * 8;
+    const int b = m / L;
+    const float mean = mr[2 * b], rstd = mr[2 * b + 1];
+    float v[8], g[8], bt[8];
+    load8(y + (long)m * ldy + c, v);
+    load8(gamma + c, g);
+    load8(beta + c, bt);
+    if (ss) {
+      float sc[8], sh[8];
+      load8(ss + (long)b * 2 * C + c, sc);
+      load8(ss + (long)b * 2 * C + C + c, sh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = silu_f(((v[e] - mean) * rstd * g[e] + bt[e]) * (1.f + sc[e]) + sh[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = silu_f((v[e] - mean) * rstd * g[e] + bt[e]);
+    }
+    store8(h + (long)m * ldh + c, v);
+  }
+}
+
+// column-reduce geometry shared by several kernels
+struct ColGeom {
+  int cp, rp;          // chunk lanes, row lanes (cp * rp <= 256)
+};
+__device__ __forceinline__ ColGeom col_geom(int chunks) {
+  ColGeom g;
+  g.cp = chunks;
+  g.rp = 256 / chunks;
+  return g;
+}
+
+// T1[b][c] = sum_n du * xhat, T2[b][c] = sum_n du   with du = dh * silu'(u)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* dh, long lddh, const T* y, long ldy, const float* mr,
+                                                            const float* gamma, const float* beta, const float* ss,
+                                                            float* T12, int C, int L, int rows_per_block) {
+  const int chunks = C >> 3;
+  const int b = blockIdx.y;
+  const ColGeom cg = col_geom(chunks);
+  const int ch = threadIdx.x % cg.cp, rl = threadIdx.x / cg.cp;
+  const int c = ch * 8;
+  const int n_begin = blockIdx.x * rows_per_block, n_end = min(L, n_begin + rows_per_block);
+  float t1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rl < cg.rp) {
+    const float mean = mr[2 * b], rstd = mr[2 * b + 1];
+    float g[8], bt[8], sc[8], sh[8];
+    load8(gamma + c, g);
+    load8(beta + c, bt);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = 0.f; sh[e] = 0.f; }
+    if (ss) { load8(ss + (long)b * 2 * C + c, sc); load8(ss + (long)b * 2 * C + C + c, sh); }
+    for (int n = n_begin + rl; n < n_end; n += cg.rp) {
+      const long m = (long)b * L + n;
+      float v[8], d[8];
+      load8(y + m * ldy + c, v);
+      load8(dh + m * lddh + c, d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float xh = (v[e] - mean) * rstd;
+        float u = (xh * g[e] + bt[e]) * (1.f + sc[e]) + sh[e];
+        float du = d[e] * silu_grad_f(u);
+        t1[e] += du * xh;
+        t2[e] += du;
+      }
+    }
+  }
+  // reduce over row lanes through LDS, then one atomic per (b, c)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);            // [2][rp][C]
+  if (rl < cg.rp) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[(0 * cg.rp + rl) * C + c + e] = t1[e]; red[(1 * cg.rp + rl) * C + c + e] = t2[e]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    const int w = i / C, cc = i - w * C;
+    float s = 0.f;
+    for (int r = 0; r < cg.rp; ++r) s += red[(w * cg.rp + r) * C + cc];
+    atomic_add_f32(T12 + ((long)b * 2 + w) * C + cc, s);
+  }
+}
+
+// per sample: S1 = sum_c gamma*(1+scale)*T2, S2 = sum_c gamma*(1+scale)*T1 ; dscale, dshift ; dgamma, dbeta (atomics over b)
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* T12, const float* gamma, const float* beta, const float* ss,
+                                                              float* S, float* dss, float* dgamma, float* dbeta, int C) {
+  const int b = blockIdx.x;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float t1 = T12[((long)b * 2 + 0) * C + c], t2 = T12[((long)b * 2 + 1) * C + c];
+    const float g = gamma[c], bt = beta[c];
+    const float k = ss ? 1.f + ss[(long)b * 2 * C + c] : 1.f;
+    s1 += g * k * t2;
+    s2 += g * k * t1;
+    if (dss) { dss[(long)b * 2 * C + c] = g * t1 + bt * t2; dss[(long)b * 2 * C + C + c] = t2; }
+    atomic_add_f32(dgamma + c, k * t1);
+    atomic_add_f32(dbeta + c, k * t2);
+  }
+  __shared__ float r1[4], r2[4];
+  s1 = group_sum<64>(s1);
+  s2 = group_sum<64>(s2);
+  if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    S[2 * b] = r1[0] + r1[1] + r1[2] + r1[3];
+    S[2 * b + 1] = r2[0] + r2[1] + r2[2] + r2[3];
+  }
+}
+
+// dy = rstd * ( gamma*(1+scale)*du - S1/cnt - xhat*S2/cnt )
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* dh, long lddh, const T* y, long ldy, T* dy, long lddy,
+                                                           const float* mr, const float* gamma, const float* beta, const float* ss,
+                                                           const float* S, int M, int C, int L, float inv_count) {
+  const int chunks = C >> 3;
+  const long total = (long)M * chunks;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(idx / chunks), c = (int)(idx - (long)m * chunks) * 8;
+    const int b = m / L;
+    const float mean = mr[2 * b], rstd = mr[2 * b + 1];
+    const float a1 = S[2 * b] * inv_count, a2 = S[2 * b + 1] * inv_count;
+    float v[8], d[8], g[8], bt[8], sc[8], sh[8];
+    load8(y + (long)m * ldy + c, v);
+    load8(dh + (long)m * lddh + c, d);
+    load8(gamma + c, g);
+    load8(beta + c, bt);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = 0.f; sh[e] = 0.f; }
+    if (ss) { load8(ss + (long)b * 2 * C + c, sc); load8(ss + (long)b * 2 * C + C + c, sh); }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float xh = (v[e] - mean) * rstd;
+      float k = 1.f + sc[e];
+      float u = (xh * g[e] + bt[e]) * k + sh[e];
+      float du = d[e] * silu_grad_f(u);
+      v[e] = rstd * (g[e] * k * du - a1 - xh * a2);
+    }
+    store8(dy + (long)m * lddy + c, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row-wise skeleton: G lanes per row (G power of two <= 64), up to 4 chunks of 8 channels per lane
+// ------------------------------------------------------------------------------------------------
+static constexpr int kMaxCh = 4;
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, long ldx, T* out, long ldo, float* mr, const float* gamma,
+                                                     const float* beta, int M, int C, int G) {
+  const int chunks = C >> 3;
+  const int rows_per_wave = 64 / G;
+  const int lane = threadIdx.x & 63, gl = lane % G, gr = lane / G;
+  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const float invC = 1.f / (float)C;
+  for (long m0 = (long)wave_global * rows_per_wave; m0 < M; m0 += (long)waves_total * rows_per_wave) {
+    const long m = m0 + gr;
+    const bool rok = m < M;
+    float v[kMaxCh][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxCh; ++j) {
+      const int ch = gl + j * G;
+      if (rok && ch < chunks) {
+        load8(x + m * ldx + ch * 8, v[j]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[j][e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+      }
+    }
+    s = group_sum_dyn(s, G);
+    const float mean = s * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxCh; ++j) {
+      const int ch = gl + j * G;
+      if (ch < chunks) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float d = v[j][e] - mean; q += d * d; }
+      }
+    }
+    q = group_sum_dyn(q, G);
+    const float rstd = rsqrtf(q * invC + kEps);
+    if (rok) {
+      if (gl == 0 && mr) { mr[2 * m] = mean; mr[2 * m + 1] = rstd; }
+#pragma unroll
+      for (int j = 0; j < kMaxCh; ++j) {
+        const int ch = gl + j * G;
+        if (ch < chunks) {
+          float g[8], bt[8], o[8];
+          load8(gamma + ch * 8, g);
+          load8(beta + ch * 8, bt);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (v[j][e] - mean) * rstd * g[e] + bt[e];
+          store8(out + m * ldo + ch * 8, o);
+        }
+      }
+    }
+  }
+}
+
+// dx = rstd * (g*dy - mean_c(g*dy) - xhat * mean_c(g*dy*xhat));  dgamma += sum_m dy*xhat; dbeta += sum_m dy
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, const T* x, long ldx, T* dx, long lddx, const float* mr,
+                                                     const float* gamma, float* dgamma, float* dbeta, int M, int C, int G) {
+  const int chunks = C >> 3;
+  const int rows_per_wave = 64 / G;
+  const int lane = threadIdx.x & 63, gl = lane % G, gr = lane / G;
+  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const float invC = 1.f / (float)C;
+  float ag[kMaxCh][8], ab[kMaxCh][8];
+#pragma unroll
+  for (int j = 0; j < kMaxCh; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; }
+  for (long m0 = (long)wave_global * rows_per_wave; m0 < M; m0 += (long)waves_total * rows_per_wave) {
+    const long m = m0 + gr;
+    const bool rok = m < M;
+    const float mean = rok ? mr[2 * m] : 0.f, rstd = rok ? mr[2 * m + 1] : 0.f;
+    float xh[kMaxCh][8], gd[kMaxCh][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxCh; ++j) {
+      const int ch = gl + j * G;
+      if (rok && ch < chunks) {
+        float xv[8], dv[8], g[8];
+        load8(x + m * ldx + ch * 8, xv);
+        load8(dy + m * lddy + ch * 8, dv);
+        load8(gamma + ch * 8, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[j][e] = (xv[e] - mean) * rstd;
+          gd[j][e] = g[e] * dv[e];
+          s1 += gd[j][e];
+          s2 += gd[j][e] * xh[j][e];
+          ag[j][e] += dv[e] * xh[j][e];
+          ab[j][e] += dv[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xh[j][e] = 0.f; gd[j][e] = 0.f; }
+      }
+    }
+    s1 = group_sum_dyn(s1, G) * invC;
+    s2 = group_sum_dyn(s2, G) * invC;
+    if (rok) {
+#pragma unroll
+      for (int j = 0; j < kMaxCh; ++j) {
+        const int ch = gl + j * G;
+        if (ch < chunks) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = rstd * (gd[j][e] - s1 - xh[j][e] * s2);
+          store8(dx + m * lddx + ch * 8, o);
+        }
+      }
+    }
+  }
+  // reduce dgamma/dbeta partials: lanes with equal gl across the wave (xor over the row-group bits), then atomics
+  for (int o = G; o < 64; o <<= 1) {
+#pragma unroll
+    for (int j = 0; j < kMaxCh; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ag[j][e] += __shfl_xor(ag[j][e], o, 64); ab[j][e] += __shfl_xor(ab[j][e], o, 64); }
+  }
+  if (gr == 0) {
+#pragma unroll
+    for (int j = 0; j < kMaxCh; ++j) {
+      const int ch = gl + j * G;
+      if (ch < chunks) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { atomic_add_f32(dgamma + ch * 8 + e, ag[j][e]); atomic_add_f32(dbeta + ch * 8 + e, ab[j][e]); }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GlobalContext
+// ------------------------------------------------------------------------------------------------
+// rowdot[m] = h[m,:] . w[b or 0][:] + bias        (w_stride = 0: shared vector (to_k); = C: per-sample vector)
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_kernel(const T* h, long ldh, const float* w, long w_stride, const float* bias,
+                                                     float* out, int M, int C, int L, int G) {
+  const int chunks = C >> 3;
+  const int rows_per_wave = 64 / G;
+  const int lane = threadIdx.x & 63, gl = lane % G, gr = lane / G;
+  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const float bv = bias ? bias[0] : 0.f;
+  for (long m0 = (long)wave_global * rows_per_wave; m0 < M; m0 += (long)waves_total * rows_per_wave) {
+    const long m = m0 + gr;
+    const bool rok = m < M;
+    const long b = rok ? m / L : 0;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxCh; ++j) {
+      const int ch = gl + j * G;
+      if (rok && ch < chunks) {
+        float v[8], wv[8];
+        load8(h + m * ldh + ch * 8, v);
+        load8(w + b * w_stride + ch * 8, wv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e] * wv[e];
+      }
+    }
+    s = group_sum_dyn(s, G);
+    if (rok && gl == 0) out[m] = s + bv;
+  }
+}
+
+// in-place softmax over the L logits of each sample (one workgroup per sample)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* p, int L) {
+  float* row = p + (long)blockIdx.x * L;
+  __shared__ float red[4];
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < L; i += 256) mx = fmaxf(mx, row[i]);
+  mx = group_max<64>(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int i = threadIdx.x; i < L; i += 256) { float e = __expf(row[i] - mx); row[i] = e; s += e; }
+  s = group_sum<64>(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float inv = 1.f / (red[0] + red[1] + red[2] + red[3]);
+  for (int i = threadIdx.x; i < L; i += 256) row[i] *= inv;
+}
+
+// out[b][c] += sum_n w[b*L+n] * a[n][c] * (bmul ? bmul[n][c] : 1)      (w may be null -> 1)
+//   pooled   = wsum(p, h)          dgate = wsum(null, dout*h)          dwk_b = wsum(dlogit, h)
+template <typename T>
+__global__ __launch_bounds__(256) void wcolsum_kernel(const T* a, long lda, const T* bmul, long ldb, const float* w, float* out,
+                                                      int C, int L, int rows_per_block) {
+  const int chunks = C >> 3;
+  const int b = blockIdx.y;
+  const ColGeom cg = col_geom(chunks);
+  const int ch = threadIdx.x % cg.cp, rl = threadIdx.x / cg.cp;
+  const int c = ch * 8;
+  const int n_begin = blockIdx.x * rows_per_block, n_end = min(L, n_begin + rows_per_block);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rl < cg.rp) {
+    for (int n = n_begin + rl; n < n_end; n += cg.rp) {
+      const long m = (long)b * L + n;
+      float v[8];
+      load8(a + m * lda + c, v);
+      if (bmul) {
+        float u[8];
+        load8(bmul + m * ldb + c, u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= u[e];
+      }
+      const float wv = w ? w[m] : 1.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += wv * v[e];
+    }
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);            // [rp][C]
+  if (rl < cg.rp) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl * C + c + e] = acc[e];
+  }
+  __syncthreads();
+  for (int cc = threadIdx.x; cc < C; cc += blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < cg.rp; ++r) s += red[r * C + cc];
+    atomic_add_f32(out + (long)b * C + cc, s);
+  }
+}
+
+// out = h * gate[b][:] + res
+template <typename T>
+__global__ __launch_bounds__(256) void gate_residual_kernel(const T* h, long ldh, const float* gate, const T* res, long ldr,
+                                                            T* out, long ldo, int M, int C, int L) {
+  const int chunks = C >> 3;
+  const long total = (long)M * chunks;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(idx / chunks), c = (int)(idx - (long)m * chunks) * 8;
+    const int b = m / L;
+    float v[8], g[8], r[8];
+    load8(h + (long)m * ldh + c, v);
+    load8(gate + (long)b * C + c, g);
+    load8(res + (long)m * ldr + c, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * g[e] + r[e];
+    store8(out + (long)m * ldo + c, v);
+  }
+}
+
+// GlobalContext backward, row-wise:
+//   dp = h[m,:].dpooled[b,:] ; dlogit = p[m] * (dp - sdot[b]) ; dh = dout*gate[b] + p[m]*dpooled[b] + dlogit*wk
+template <typename T>
+__global__ __launch_bounds__(256) void gca_bwd_apply_kernel(const T* dout, long lddo, const T* h, long ldh, T* dh, long lddh,
+                                                            const float* p, const float* gate, const float* dpooled,
+                                                            const float* sdot, const float* wk, float* dlogit,
+                                                            int M, int C, int L, int G) {
+  const int chunks = C >> 3;
+  const int rows_per_wave = 64 / G;
+  const int lane = threadIdx.x & 63, gl = lane % G, gr = lane / G;
+  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  for (long m0 = (long)wave_global * rows_per_wave; m0 < M; m0 += (long)waves_total * rows_per_wave) {
+    const long m = m0 + gr;
+    const bool rok = m < M;
+    const long b = rok ? m / L : 0;
+    float hv[kMaxCh][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxCh; ++j) {
+      const int ch = gl + j * G;
+      if (rok && ch < chunks) {
+        float dp[8];
+        load8(h + m * ldh + ch * 8, hv[j]);
+        load8(dpooled + b * C + ch * 8, dp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += hv[j][e] * dp[e];
+      }
+    }
+    s = group_sum_dyn(s, G);
+    if (rok) {
+      const float pm = p[m];
+      const float dl = pm * (s - sdot[b]);
+      if (gl == 0) dlogit[m] = dl;
+#pragma unroll
+      for (int j = 0; j < kMaxCh; ++j) {
+        const int ch = gl + j * G;
+        if (ch < chunks) {
+          float d[8], g[8], dp[8], w[8], o[8];
+          load8(dout + m * lddo + ch * 8, d);
+          load8(gate + b * C + ch * 8, g);
+          load8(dpooled + b * C + ch * 8, dp);
+          load8(wk + ch * 8, w);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = d[e] * g[e] + pm * dp[e] + dl * w[e];
+          store8(dh + m * lddh + ch * 8, o);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static inline int pick_group(int chunks) {
+  int g = 1;
+  while (g < chunks && g < 64) g <<= 1;
+  return g;
+}
+static inline int ew_grid(long total_threads) {
+  long blocks = (total_threads + 255) / 256;
+  if (blocks > 2048) blocks = 2048;                   // 256 CUs x 8, grid-stride the rest
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+static inline int row_grid(long M, int G) {
+  long rows_per_block = 4L * (64 / G);
+  long blocks = (M + rows_per_block - 1) / rows_per_block;
+  if (blocks > 4096) blocks = 4096;
+  return (int)blocks;
+}
+#define DISPATCH_T(dtype, ...)                                  \
+  if ((dtype) == OSUF_DT_BF16) { using T = bf16_t; __VA_ARGS__; } \
+  else if ((dtype) == OSUF_DT_F32) { using T = float; __VA_ARGS__; } \
+  else return OSUF_EUNSUPPORTED;
+
+static inline bool bad_c(int C) { return C <= 0 || (C & 7) || C > 8 * 256; }
+
+extern "C" int osuf_gn_finalize(const double* stats, float* mr, int B, long count, hipStream_t stream) {
+  if (B <= 0 || count <= 0) return OSUF_EINVAL;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, stats, mr, B, 1.0 / (double)count);
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_gn_apply_fwd(int dtype, const void* y, long ldy, void* h, long ldh, const float* mr, const float* gamma,
+                                 const float* beta, const float* ss, int M, int C, int L, hipStream_t stream) {
+  if (bad_c(C) || M <= 0 || L <= 0 || M % L || ldy % 8 || ldh % 8) return OSUF_EINVAL;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gn_apply_fwd_kernel<T>, dim3(ew_grid((long)M * (C / 8))), dim3(256), 0, stream,
+                                       (const T*)y, ldy, (T*)h, ldh, mr, gamma, beta, ss, M, C, L));
+  return osuf_launch_status();
+}
+
+// T12: [B][2][C] fp32, must be zero on entry.  dss may be null (no FiLM).  dgamma/dbeta are accumulated into.
+extern "C" int osuf_gn_bwd(int dtype, const void* dh, long lddh, const void* y, long ldy, void* dy, long lddy, const float* mr,
+                           const float* gamma, const float* beta, const float* ss, float* T12, float* S, float* dss,
+                           float* dgamma, float* dbeta, int M, int C, int L, hipStream_t stream) {
+  if (bad_c(C) || M <= 0 || L <= 0 || M % L || ldy % 8 || lddh % 8 || lddy % 8) return OSUF_EINVAL;
+  const int B = M / L;
+  const int chunks = C / 8;
+  const int rp = 256 / chunks;
+  const int rows_per_block = 64;
+  const size_t lds = (size_t)2 * rp * C * sizeof(float);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gn_bwd_reduce_kernel<T>, dim3((L + rows_per_block - 1) / rows_per_block, B), dim3(256), lds,
+                                       stream, (const T*)dh, lddh, (const T*)y, ldy, mr, gamma, beta, ss, T12, C, L, rows_per_block));
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, stream, T12, gamma, beta, ss, S, dss, dgamma, dbeta, C);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(ew_grid((long)M * chunks)), dim3(256), 0, stream, (const T*)dh,
+                                       lddh, (const T*)y, ldy, (T*)dy, lddy, mr, gamma, beta, ss, S, M, C, L,
+                                       1.0f / ((float)L * (float)C)));
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_ln_fwd(int dtype, const void* x, long ldx, void* out, long ldo, float* mr, const float* gamma, const float* beta,
+                           int M, int C, hipStream_t stream) {
+  if (bad_c(C) || M <= 0 || ldx % 8 || ldo % 8) return OSUF_EINVAL;
+  const int G = pick_group(C / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(ln_fwd_kernel<T>, dim3(row_grid(M, G)), dim3(256), 0, stream, (const T*)x, ldx, (T*)out, ldo,
+                                       mr, gamma, beta, M, C, G));
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_ln_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, void* dx, long lddx, const float* mr,
+                           const float* gamma, float* dgamma, float* dbeta, int M, int C, hipStream_t stream) {
+  if (bad_c(C) || M <= 0 || ldx % 8 || lddy % 8 || lddx % 8) return OSUF_EINVAL;
+  const int G = pick_group(C / 8);
+  long blocks = row_grid(M, G);
+  if (blocks > 1024) blocks = 1024;                   // bounds the dgamma/dbeta atomic traffic
+  DISPATCH_T(dtype, hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3((int)blocks), dim3(256), 0, stream, (const T*)dy, lddy, (const T*)x, ldx,
+                                       (T*)dx, lddx, mr, gamma, dgamma, dbeta, M, C, G));
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_rowdot(int dtype, const void* h, long ldh, const float* w, long w_stride, const float* bias, float* out,
+                           int M, int C, int L, hipStream_t stream) {
+  if (bad_c(C) || M <= 0 || L <= 0 || ldh % 8 || w_stride % 8) return OSUF_EINVAL;
+  const int G = pick_group(C / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(rowdot_kernel<T>, dim3(row_grid(M, G)), dim3(256), 0, stream, (const T*)h, ldh, w, w_stride,
+                                       bias, out, M, C, L, G));
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_softmax_rows(float* p, int B, int L, hipStream_t stream) {
+  if (B <= 0 || L <= 0) return OSUF_EINVAL;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(B), dim3(256), 0, stream, p, L);
+  return osuf_launch_status();
+}
+
+// out [B][C] fp32 is accumulated into (zero it first)
+extern "C" int osuf_wcolsum(int dtype, const void* a, long lda, const void* bmul, long ldb, const float* w, float* out,
+                            int B, int C, int L, hipStream_t stream) {
+  if (bad_c(C) || B <= 0 || L <= 0 || lda % 8 || (bmul && ldb % 8)) return OSUF_EINVAL;
+  const int rp = 256 / (C / 8);
+  const int rows_per_block = 64;
+  const size_t lds = (size_t)rp * C * sizeof(float);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(wcolsum_kernel<T>, dim3((L + rows_per_block - 1) / rows_per_block, B), dim3(256), lds, stream,
+                                       (const T*)a, lda, (const T*)bmul, ldb, w, out, C, L, rows_per_block));
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_gate_residual(int dtype, const void* h, long ldh, const float* gate, const void* res, long ldr, void* out, long ldo,
+                                  int M, int C, int L, hipStream_t stream) {
+  if (bad_c(C) || M <= 0 || L <= 0 || M % L || ldh % 8 || ldr % 8 || ldo % 8) return OSUF_EINVAL;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gate_residual_kernel<T>, dim3(ew_grid((long)M * (C / 8))), dim3(256), 0, stream, (const T*)h, ldh,
+                                       gate, (const T*)res, ldr, (T*)out, ldo, M, C, L));
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_gca_bwd_apply(int dtype, const void* dout, long lddo, const void* h, long ldh, void* dh, long lddh, const float* p,
+                                  const float* gate, const float* dpooled, const float* sdot, const float* wk, float* dlogit,
+                                  int M, int C, int L, hipStream_t stream) {
+  if (bad_c(C) || M <= 0 || L <= 0 || M % L || lddo % 8 || ldh % 8 || lddh % 8) return OSUF_EINVAL;
+  const int G = pick_group(C / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gca_bwd_apply_kernel<T>, dim3(row_grid(M, G)), dim3(256), 0, stream, (const T*)dout, lddo,
+                                       (const T*)h, ldh, (T*)dh, lddh, p, gate, dpooled, sdot, wk, dlogit, M, C, L, G));
+  return osuf_launch_status();
+}

@@ -1,0 +1,370 @@
+"""autograd.Functions over the HIP kernels: one Function per reference block, backward hand-scheduled.
+
+Tensors between Functions are channels-last "rows" (B, L, C) in the compute dtype (bf16 or fp32).  Parameters
+stay fp32 masters; GEMM operands are packed per (layout, dtype) and cached until the weights change.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import ops
+
+_WEIGHT_EPOCH = 0          # bumped by the fused optimizer (it writes parameters through raw pointers)
+
+
+def bump_weight_epoch() -> None:
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+
+
+class PackCache:
+    """Per-module cache of GEMM-ready weight layouts, invalidated when any source parameter changes."""
+
+    def __init__(self) -> None:
+        self._d: Dict[Tuple, Tuple[Tuple, torch.Tensor]] = {}
+
+    def get(self, key: Tuple, params: Tuple[torch.Tensor, ...], builder) -> torch.Tensor:
+        ver = (_WEIGHT_EPOCH, *[(p._version, p.data_ptr()) for p in params])
+        hit = self._d.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            t = builder().contiguous()
+        self._d[key] = (ver, t)
+        return t
+
+
+def _rc(t: torch.Tensor) -> torch.Tensor:
+    """Make a grad tensor kernel-consumable (last dim contiguous, dense rows, 16-B aligned)."""
+    if t.stride(-1) != 1 or (t.dim() == 3 and t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1)) or t.data_ptr() % 16:
+        return t.contiguous()
+    if t.dim() == 3 and t.stride(1) % 8:
+        return t.contiguous()
+    return t
+
+
+# pack builders -------------------------------------------------------------------------------------------
+def pack_fwd(w: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
+    """(Cout, Cin, k) -> [k][Cout][Cin];  (out, in) -> [1][out][in]."""
+    if w.dim() == 2:
+        return w.detach().to(dt).unsqueeze(0)
+    return w.detach().permute(2, 0, 1).to(dt)
+
+
+def pack_dgrad(w: torch.Tensor, dt: torch.dtype, kind: str = "same") -> torch.Tensor:
+    """Weights of the input-gradient conv, [taps'][Cin][Cout] (see gemm.hip row-map modes)."""
+    if w.dim() == 2:
+        return w.detach().t().to(dt).unsqueeze(0)
+    wt = w.detach().permute(2, 1, 0)                       # [k][Cin][Cout]
+    if kind == "same":
+        return wt.flip(0).to(dt)
+    if kind == "down":                                     # mode 3: taps 0..2 as is, tap 3 = reflected column (W_2)
+        return torch.cat([wt, wt[2:3]], 0).to(dt)
+    if kind == "up":                                       # nearest-x2 + k3  ->  4-tap stride-2 conv over dy
+        return torch.stack([wt[2], wt[1] + wt[2], wt[0] + wt[1], wt[0]], 0).to(dt)
+    raise ValueError(kind)
+
+
+_CONV_KINDS = {
+    # kind: fwd (stride, mode), dgrad (taps, stride, pad, mode)
+    "same": dict(stride=1, mode=0),
+    "down": dict(stride=2, mode=1),
+    "up": dict(stride=1, mode=2),
+}
+
+
+def _conv_geom(kind: str, k: int, Lin: int) -> Tuple[int, int, int, int]:
+    """-> (Lout, stride, pad, mode) of the forward row map."""
+    if kind == "same":
+        return Lin, 1, k // 2, 0
+    if kind == "down":
+        if Lin % 2:
+            raise ValueError("Downsample needs an even length (UNet pads to a multiple of 2^depth)")
+        return Lin // 2, 2, 0, 1
+    if kind == "up":
+        return 2 * Lin, 1, 1, 2
+    raise ValueError(kind)
+
+
+def _vkey(vp, w):
+    """vp = (tag, *source_params) for weights derived on the fly (merged stems, Parallel, padded heads)."""
+    return (vp[0], tuple(vp[1:])) if vp is not None else ("", (w,))
+
+
+def conv_forward(x, w, bias, cache: PackCache, kind: str, vp=None, **epi):
+    B, Lin, Cin = x.shape
+    k = w.shape[2] if w.dim() == 3 else 1
+    Lout, stride, pad, mode = _conv_geom(kind, k, Lin)
+    tag, vparams = _vkey(vp, w)
+    wp = cache.get(("f", kind, x.dtype, tag), vparams, lambda: pack_fwd(w, x.dtype))
+    return ops.gemm_nt(x, wp, bias, taps=k, lin=Lin, lout=Lout, stride=stride, pad=pad, mode=mode, out_shape=(B, Lout, wp.shape[1]), **epi)
+
+
+def conv_dgrad(dy, w, cache: PackCache, kind: str, Lin: int, residual=None, vp=None):
+    """Input gradient of conv_forward: dy rows (B, Lout, Cout) -> (B, Lin, Cin)."""
+    B, Lout, Cout = dy.shape
+    k = w.shape[2] if w.dim() == 3 else 1
+    tag, vparams = _vkey(vp, w)
+    wp = cache.get(("d", kind, dy.dtype, tag), vparams, lambda: pack_dgrad(w, dy.dtype, kind))
+    Cin = wp.shape[1]
+    if kind == "same":
+        geom = dict(taps=k, stride=1, pad=k - 1 - k // 2, mode=0)
+    elif kind == "down":
+        geom = dict(taps=4, stride=1, pad=0, mode=3)
+    else:
+        geom = dict(taps=4, stride=2, pad=1, mode=0)
+    return ops.gemm_nt(dy, wp, None, lin=Lout, lout=Lin, residual=residual, out_shape=(B, Lin, Cin), **geom)
+
+
+def conv_wgrad(dy, x, w, kind: str):
+    """-> gradient tensor shaped like w."""
+    B, Lin, Cin = x.shape
+    k = w.shape[2] if w.dim() == 3 else 1
+    Lout, stride, pad, mode = _conv_geom(kind, k, Lin)
+    g = ops.gemm_tn(dy, x, taps=k, lin=Lin, lout=Lout, stride=stride, pad=pad, mode=mode, n1=w.shape[0])   # [k][Cout][Cin]
+    return g[0] if w.dim() == 2 else g.permute(1, 2, 0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+class ConvFn(torch.autograd.Function):
+    """Conv1d (same / Downsample / Upsample geometry) or Linear on rows.  unet.py:61-101, residual.py:115."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, cache, kind, vp=None):
+        ctx.save_for_backward(x, w)
+        ctx.cache, ctx.kind, ctx.has_bias, ctx.vp = cache, kind, bias is not None, vp
+        return conv_forward(x, w, bias, cache, kind, vp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _rc(dy)
+        dx = conv_dgrad(dy, w, ctx.cache, ctx.kind, x.shape[1], vp=ctx.vp) if ctx.needs_input_grad[0] else None
+        dw = conv_wgrad(dy, x, w, ctx.kind) if ctx.needs_input_grad[1] else None
+        db = ops.colsum(dy, w.shape[0]) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None, None
+
+
+class BlockFn(torch.autograd.Function):
+    """conv k3 -> GroupNorm(1,C) -> FiLM -> SiLU   (residual.py:75-84).  ss: fp32 (B, 2C) = (scale | shift) or None."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, gamma, beta, ss, cache):
+        B, L, _ = x.shape
+        C = w.shape[0]
+        stats = torch.zeros((B, 2), dtype=torch.float64, device=x.device)
+        y = conv_forward(x, w, bias, cache, "same", None, stats=stats)
+        mr = ops.gn_finalize(stats, L * C)
+        ssc = ss.contiguous() if ss is not None else None
+        h = ops.gn_apply(y, mr, gamma, beta, ssc, L)
+        ctx.save_for_backward(x, w, y, mr, gamma, beta, ssc if ssc is not None else mr)
+        ctx.cache, ctx.has_ss = cache, ss is not None
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, w, y, mr, gamma, beta, ss = ctx.saved_tensors
+        ss = ss if ctx.has_ss else None
+        L = x.shape[1]
+        dy, dgamma, dbeta, dss = ops.gn_bwd(_rc(dh), y, mr, gamma, beta, ss, L)
+        dx = conv_dgrad(dy, w, ctx.cache, "same", L) if ctx.needs_input_grad[0] else None
+        dw = conv_wgrad(dy, x, w, "same")
+        db = ops.colsum(dy)
+        return dx, dw, db, dgamma, dbeta, dss, None
+
+
+class GCAPoolFn(torch.autograd.Function):
+    """GlobalContext pooling: pooled[b,c] = sum_n softmax_n(h.wk + bk)[n] * h[b,n,c]   (residual.py:29-31) -> fp32 (B,C)."""
+
+    @staticmethod
+    def forward(ctx, h, wk, bk):
+        B, L, C = h.shape
+        wkv = wk.reshape(-1).contiguous()
+        p = ops.rowdot(h, wkv, bk.reshape(-1), L)
+        ops.softmax_rows_(p, B, L)
+        pooled = ops.wcolsum(h, None, p, B, L)
+        ctx.save_for_backward(h, wkv, p, pooled)
+        ctx.wshape = wk.shape
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        h, wkv, p, pooled = ctx.saved_tensors
+        B, L, C = h.shape
+        dpooled = dpooled.contiguous().float()
+        sdot = (pooled * dpooled).sum(1).contiguous()
+        zero_gate = torch.zeros((B, C), dtype=torch.float32, device=h.device)
+        # dh = p*dpooled + dlogit*wk  (the `dout*gate` term of the fused kernel is disabled with a zero gate)
+        dh, dlogit = ops.gca_bwd_apply(h, h, p, zero_gate, dpooled, sdot, wkv, L)
+        dwk = ops.wcolsum(h, None, dlogit, B, L).sum(0)
+        dbk = dlogit.sum().reshape(1)
+        return dh, dwk.reshape(ctx.wshape), dbk
+
+
+class GateResFn(torch.autograd.Function):
+    """out = h * gate + res   (residual.py:135-137, identity res_conv).  gate fp32 (B, C)."""
+
+    @staticmethod
+    def forward(ctx, h, gate, res):
+        L = h.shape[1]
+        gate = gate.contiguous()
+        ctx.save_for_backward(h, gate)
+        return ops.gate_residual(h, gate, res, L)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, gate = ctx.saved_tensors
+        B, L, C = h.shape
+        dout = _rc(dout)
+        dgate = ops.wcolsum(dout, h, None, B, L)
+        zero = torch.zeros_like(dout)
+        dh = ops.gate_residual(dout, gate, zero, L)                 # dout * gate
+        return dh, dgate, dout
+
+
+class GateResConvFn(torch.autograd.Function):
+    """out = h * gate + res_conv(x)  (residual.py:135-137, 1x1 res_conv): the gate-multiply rides the GEMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, h, gate, x, w, bias, cache):
+        gate = gate.contiguous()
+        ctx.save_for_backward(h, gate, x, w)
+        ctx.cache = cache
+        return conv_forward(x, w, bias, cache, "same", None, residual=h, rscale=gate)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, gate, x, w = ctx.saved_tensors
+        B, L, C = h.shape
+        dout = _rc(dout)
+        dgate = ops.wcolsum(dout, h, None, B, L)
+        dh = ops.gate_residual(dout, gate, torch.zeros_like(dout), L)
+        dx = conv_dgrad(dout, w, ctx.cache, "same", L)
+        dw = conv_wgrad(dout, x, w, "same")
+        db = ops.colsum(dout)
+        return dh, dgate, dx, dw, db, None
+
+
+class FeedForwardFn(torch.autograd.Function):
+    """x + W2 silu(W1 x + b1) + b2   (unet.py:149-156,182): SiLU and the residual ride the GEMM epilogues."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, cache):
+        h, pre = conv_forward(x, w1, b1, cache, "same", None, act=1, want_pre=True)
+        wp2 = cache.get(("f2", x.dtype), (w2,), lambda: pack_fwd(w2, x.dtype))
+        out = ops.gemm_nt(h, wp2, b2, residual=x, out_shape=x.shape)
+        ctx.save_for_backward(x, w1, w2, h, pre)
+        ctx.cache = cache
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w1, w2, h, pre = ctx.saved_tensors
+        dout = _rc(dout)
+        cache = ctx.cache
+        wd2 = cache.get(("d2", x.dtype), (w2,), lambda: pack_dgrad(w2, x.dtype))
+        dpre = ops.gemm_nt(dout, wd2, None, dact=pre, out_shape=pre.shape)          # (dout W2) * silu'(pre)
+        dw2 = ops.gemm_tn(dout, h)[0]
+        db2 = ops.colsum(dout)
+        dw1 = ops.gemm_tn(dpre, x)[0]
+        db1 = ops.colsum(dpre)
+        wd1 = cache.get(("d", "same", x.dtype), (w1,), lambda: pack_dgrad(w1, x.dtype))
+        dx = ops.gemm_nt(dpre, wd1, None, residual=dout, out_shape=x.shape)
+        return dx, dw1, db1, dw2, db2, None
+
+
+_ROPE_TABLES: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def rope_tables(n: int, dim: int, scale_base: int, device, theta: float = 10000.0):
+    """cos/sin tables [n][dim/2] in fp32, built exactly as attention.py:24-47 does for an fp32 q (on the host)."""
+    key = (n, dim, scale_base, str(device))
+    hit = _ROPE_TABLES.get(key)
+    if hit is None:
+        inv_freq = 1.0 / (theta ** (torch.arange(0, dim, 2).float() / dim))
+        t = torch.arange(n, dtype=torch.float32)
+        t *= scale_base / n
+        freqs = torch.einsum("i , j -> i j", t, inv_freq)
+        hit = (freqs.cos().contiguous().to(device), freqs.sin().contiguous().to(device))
+        _ROPE_TABLES[key] = hit
+    return hit
+
+
+class AttentionFn(torch.autograd.Function):
+    """LayerNorm -> to_q/to_kv -> RoPE -> MQA flash attention -> to_out + residual(normed x)   (unet.py:125-141)."""
+
+    @staticmethod
+    def forward(ctx, x, nw, nb, wq, wkv, wo, bo, cache, heads, dim_head, scale_base):
+        B, N, C = x.shape
+        H, D = heads, dim_head
+        dt = x.dtype
+        xn, mr = ops.ln_fwd(x, nw, nb)
+        wqkv = cache.get(("qkv", dt), (wq, wkv), lambda: torch.cat([wq.detach(), wkv.detach()], 0).to(dt).unsqueeze(0))
+        qkv = ops.gemm_nt(xn, wqkv, None, out_shape=(B, N, (H + 2) * D))
+        cos, sin = rope_tables(N, D, scale_base, x.device)
+        qkv_r = ops.rope_cast(qkv, cos, sin, N, H + 1, H + 2, D)                # rotate q heads and k; cast v
+        del qkv
+        scale = D ** -0.5
+        o, lse = ops.mqa_fwd(qkv_r, B, N, H, D, dt, scale)
+        wpo = cache.get(("fo", dt), (wo,), lambda: pack_fwd(wo, dt))
+        out = ops.gemm_nt(o, wpo, bo, residual=xn, out_shape=x.shape)
+        ctx.save_for_backward(x, nw, mr, xn, wq, wkv, wo, qkv_r, o, lse)
+        ctx.cache, ctx.geom = cache, (H, D, scale_base, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, nw, mr, xn, wq, wkv, wo, qkv_r, o, lse = ctx.saved_tensors
+        H, D, scale_base, scale = ctx.geom
+        cache = ctx.cache
+        B, N, C = x.shape
+        dt = x.dtype
+        dout = _rc(dout)
+        # to_out
+        dwo = ops.gemm_tn(dout, o)[0]
+        dbo = ops.colsum(dout)
+        wdo = cache.get(("do", dt), (wo,), lambda: pack_dgrad(wo, dt))
+        do = ops.gemm_nt(dout, wdo, None, out_shape=o.shape)
+        do16 = ops.cast_rows(do, torch.bfloat16)                                 # SDPA backward runs in bf16 (attention.py:101)
+        # attention + rope
+        dqkv32 = ops.mqa_bwd(qkv_r, o, do16, lse, B, N, H, D, scale)
+        cos, sin = rope_tables(N, D, scale_base, x.device)
+        dqkv = ops.rope_bwd(dqkv32, dt, cos, sin, N, H + 1, H + 2, D)
+        del dqkv32
+        # to_q / to_kv
+        dwqkv = ops.gemm_tn(dqkv, xn)[0]
+        wdqkv = cache.get(("dqkv", dt), (wq, wkv), lambda: torch.cat([wq.detach(), wkv.detach()], 0).t().to(dt).unsqueeze(0))
+        dxn = ops.gemm_nt(dqkv, wdqkv, None, residual=dout, out_shape=x.shape)   # + residual path (x + to_out(..), x = normed)
+        dx, dnw, dnb = ops.ln_bwd(dxn, x, mr, nw)
+        return dx, dnw, dnb, dwqkv[: H * D], dwqkv[H * D:], dwo, dbo, None, None, None, None
+
+
+class RowsFromNCLFn(torch.autograd.Function):
+    """(B, C, L) fp32 -> rows (B, L, width) in the compute dtype [im2col over kt taps]; model-boundary layout change."""
+
+    @staticmethod
+    def forward(ctx, x, dtype, width, kt):
+        ctx.shape, ctx.kt = x.shape, kt
+        return ops.ncl_to_rows(x.contiguous().float(), dtype, width, kt)
+
+    @staticmethod
+    def backward(ctx, d):
+        if ctx.kt != 1:
+            raise NotImplementedError("gradient w.r.t. the raw x input of the im2col stem is not provided")
+        return ops.rows_to_ncl(_rc(d), ctx.shape[1]), None, None, None
+
+
+class NCLFromRowsFn(torch.autograd.Function):
+    """rows (B, L, >=C) -> (B, C, L) fp32."""
+
+    @staticmethod
+    def forward(ctx, rows, C):
+        ctx.meta = (rows.dtype, rows.shape[2])
+        return ops.rows_to_ncl(rows, C)
+
+    @staticmethod
+    def backward(ctx, d):
+        dtype, width = ctx.meta
+        return ops.ncl_to_rows(d.contiguous().float(), dtype, width, 1), None

@@ -1,0 +1,147 @@
+"""HIP-backed mirror of osu_fusion/models/diffusion.py: ``OsuFusion`` with the same ctor, ``forward`` (training loss),
+``sample`` (DDIM + classifier-free guidance), ``set_full_bf16`` and the ``unet`` / ``sampling_timesteps`` attributes.
+
+The DDIM arithmetic of diffusers==0.29.2's ``DDIMScheduler`` (absent from this image) is restated in ``DDIMSchedule``
+(linear betas 1e-4..0.02, 1000 train steps, "leading" spacing, eta=0, epsilon prediction, clip_sample=True,
+set_alpha_to_one=True) and executed by the osuf_axpby_rows / osuf_ddim_step kernels.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F  # noqa: N812
+
+from .. import ops
+from .. import runtime as rt
+from ..modules.unet import UNet
+
+TOTAL_DIM = 6        # library/osu/data/encode.py:10-26
+AUDIO_DIM = 96       # scripts/dataset_creator.py:22-24
+CONTEXT_DIM = 5      # scripts/dataset_creator.py:25
+
+
+class DDIMSchedule:
+    """Restatement of the DDIMScheduler calls made at diffusion.py:48-51,71,75,96."""
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 1e-4, beta_end: float = 0.02) -> None:
+        self.num_train_timesteps = num_train_timesteps
+        betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0)
+        self.timesteps = torch.arange(num_train_timesteps).flip(0)
+        self.num_inference_steps: Optional[int] = None
+        self._dev = {}
+
+    def _acp(self, device) -> torch.Tensor:
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = self.alphas_cumprod.to(device)
+        return self._dev[key]
+
+    def set_timesteps(self, num_inference_steps: int) -> None:
+        self.num_inference_steps = num_inference_steps
+        ratio = self.num_train_timesteps // num_inference_steps
+        self.timesteps = (torch.arange(num_inference_steps) * ratio).flip(0).to(torch.int64)
+
+    def add_noise(self, x: torch.Tensor, noise: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+        acp = self._acp(x.device)[timesteps]
+        return ops.axpby_rows(x.contiguous().float(), noise.contiguous().float(), (acp ** 0.5).contiguous(), ((1 - acp) ** 0.5).contiguous())
+
+    def step_coefficients(self, t: int) -> Tuple[float, float, float, float]:
+        prev_t = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        return (float((1 - a_t) ** 0.5), float(a_t ** 0.5), float(a_prev ** 0.5), float((1 - a_prev) ** 0.5))
+
+
+class _MSEFn(torch.autograd.Function):
+    """F.mse_loss(pred, target, 'none') (* length mask).sum() / count   (diffusion.py:101-111) in one pass."""
+
+    @staticmethod
+    def forward(ctx, pred, target, orig_len):
+        acc, grad = ops.mse(pred.contiguous(), target.contiguous(), orig_len, pred.requires_grad)
+        B, Dc, L = pred.shape
+        if orig_len is not None:
+            count = orig_len.to(pred.device).clamp(max=L).sum().double() * Dc
+        else:
+            count = torch.tensor(float(B * Dc * L), dtype=torch.float64, device=pred.device)
+        ctx.save_for_backward(grad if grad is not None else acc, count)
+        return (acc / count).float().reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, count = ctx.saved_tensors
+        return grad * (g / count.float()), None, None
+
+
+class OsuFusion(nn.Module):
+    def __init__(self, dim_h: int, dim_h_mult: Tuple[int] = (1, 2, 3, 4), num_layer_blocks: Tuple[int] = (3, 3, 3, 3),
+                 num_middle_transformers: int = 3, cross_embed_kernel_sizes: Tuple[int] = (3, 7, 15), attn_dim_head: int = 64,
+                 attn_heads: int = 16, attn_kv_heads: int = 1, attn_context_len: int = 4096, cond_drop_prob: float = 0.5,
+                 train_timesteps: int = 1000, sampling_timesteps: int = 35) -> None:
+        super().__init__()
+        self.unet = UNet(dim_in_x=TOTAL_DIM, dim_in_a=AUDIO_DIM, dim_in_c=CONTEXT_DIM, dim_h=dim_h, dim_h_mult=dim_h_mult,
+                         num_layer_blocks=num_layer_blocks, num_middle_transformers=num_middle_transformers,
+                         cross_embed_kernel_sizes=cross_embed_kernel_sizes, attn_dim_head=attn_dim_head, attn_heads=attn_heads,
+                         attn_kv_heads=attn_kv_heads, attn_context_len=attn_context_len)
+        self.scheduler = DDIMSchedule(num_train_timesteps=train_timesteps)
+        self.train_timesteps = train_timesteps
+        self.sampling_timesteps = sampling_timesteps
+        self.cond_drop_prob = cond_drop_prob
+        self._full_bf16 = False
+
+    def set_full_bf16(self) -> None:
+        """diffusion.py:56-57 casts the UNet weights to bf16; here the fp32 masters are kept and every kernel computes in
+        bf16 (bf16 MFMA operands and activations) -- the same arithmetic, without losing the master weights."""
+        self._full_bf16 = True
+
+    def _dtype_ctx(self):
+        return rt.forced_compute_dtype(torch.bfloat16 if self._full_bf16 else None)
+
+    @torch.inference_mode()
+    def sample(self, a: torch.Tensor, c: torch.Tensor, x: Optional[torch.Tensor] = None, cond_scale: float = 7.0) -> torch.Tensor:
+        """diffusion.py:59-77.  Same outputs, restructured: the audio code is computed once (it does not depend on t or x),
+        the conditional and null branches of classifier-free guidance run as one batch of 2B, and the guidance combine is
+        fused into the DDIM-step kernel."""
+        (b, _, n), device = a.shape, a.device
+        rt.require_gpu(a)
+        if x is None:
+            x = torch.randn((b, TOTAL_DIM, n), device=device)
+        x = x.float().contiguous()
+        unet = self.unet
+        self.scheduler.set_timesteps(self.sampling_timesteps)
+        depth = len(unet.down_layers)
+        pad_len = (2 ** depth - (n % (2 ** depth))) % (2 ** depth)
+        cfg = cond_scale != 1.0
+        with self._dtype_ctx():
+            dtype = rt.compute_dtype(unet.final_conv.weight.dtype)
+            a_rows = unet.encode_audio(a, pad_len, dtype)
+            keep = torch.ones(b, dtype=torch.bool, device=device)
+            if cfg:
+                a_rows = torch.cat([a_rows, a_rows], 0)
+                ce = unet.embed_cond(torch.cat([c, c], 0), torch.cat([keep, ~keep], 0))
+            else:
+                ce = unet.embed_cond(c, keep)
+            for t in self.scheduler.timesteps.tolist():
+                xin = torch.cat([x, x], 0) if cfg else x
+                t_batched = torch.full((xin.shape[0],), t, dtype=torch.int64, device=device)
+                x_rows = unet.init_x.forward_rows(F.pad(xin, (0, pad_len), value=-1.0), dtype)
+                pred = unet.denoise_rows(x_rows, a_rows, unet.embed_time(t_batched), ce)[:, :, :n].contiguous()
+                coef = torch.tensor([self.scheduler.step_coefficients(t)] * b, dtype=torch.float32, device=device)
+                x = ops.ddim_step(x, pred[:b], pred[b:] if cfg else None, cond_scale, coef)
+        return x
+
+    def forward(self, x: torch.Tensor, a: torch.Tensor, c: torch.Tensor, orig_len: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert x.shape[-1] == a.shape[-1], "x and a must have the same number of sequence length"
+        rt.require_gpu(x)
+        noise = torch.randn_like(x, device=x.device)
+        timesteps = torch.randint(0, self.scheduler.num_train_timesteps, (x.shape[0],), dtype=torch.int64, device=x.device)
+        return self.loss_with(x, a, c, noise, timesteps, orig_len)
+
+    def loss_with(self, x, a, c, noise, timesteps, orig_len=None, cond_drop_prob: Optional[float] = None) -> torch.Tensor:
+        """forward() with the RNG draws passed in (parity tests, benchmarks)."""
+        p = self.cond_drop_prob if cond_drop_prob is None else cond_drop_prob
+        with self._dtype_ctx():
+            x_noisy = self.scheduler.add_noise(x, noise, timesteps)
+            pred = self.unet(x_noisy, a, timesteps, c, cond_drop_prob=p)
+        return _MSEFn.apply(pred, noise.float(), orig_len)

@@ -1,0 +1,57 @@
+"""HIP-backed mirror of osu_fusion/modules/attention.py.
+
+``RotaryPositionEmbedding`` and ``Attend`` keep the reference's call signatures on (B, H, N, D) tensors; the UNet's
+own Attention block does not go through them (it uses the fused LN -> QKV -> RoPE -> flash path of functional.py),
+they exist so code written against the reference's attention.py keeps working on the HIP kernels.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from .. import ops
+from .. import runtime as rt
+
+
+class RotaryPositionEmbedding(nn.Module):
+    """attention.py:15-58: positions rescaled by scale_base / seq_len, half-split rotation."""
+
+    def __init__(self, dim: int, theta: int = 10000, scale_base: int = 4096) -> None:
+        super().__init__()
+        self.dim, self.theta, self.scale_base = dim, theta, scale_base
+        inv_freq = 1.0 / (theta ** (torch.arange(0, dim, 2).float() / dim))
+        self.register_buffer("inv_freq", inv_freq, persistent=False)
+
+    def forward(self, q: torch.Tensor, k: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        rt.require_gpu(q)
+        if self.dim != 64:
+            raise NotImplementedError("HIP RoPE kernel is built for head_dim 64")
+        cos, sin = Fn.rope_tables(q.shape[-2], self.dim, self.scale_base, q.device, float(self.theta))
+        return _rope_bhnd(q, cos, sin), _rope_bhnd(k, cos, sin)
+
+
+def _rope_bhnd(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    B, H, N, D = x.shape
+    rows = x.permute(0, 2, 1, 3).reshape(B, N, H * D).contiguous()
+    if rows.dtype not in (torch.float32, torch.bfloat16):
+        rows = rows.float()
+    out = ops.rope_cast(rows, cos, sin, N, H, H, D)                     # bf16, as Attend would cast it next
+    return out.view(B, N, H, D).permute(0, 2, 1, 3).to(x.dtype)
+
+
+class Attend(nn.Module):
+    """attention.py:61-101: q, k, v -> bf16, softmax(q k^T / sqrt(d)) v, back to the input dtype.  Inference only here."""
+
+    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        rt.require_gpu(q)
+        if attn_mask is not None:
+            raise NotImplementedError("the UNet never passes a mask; the HIP kernel has none")
+        B, H, N, D = q.shape
+        if D != 64:
+            raise NotImplementedError("HIP attention kernel is built for head_dim 64")
+        if k.shape[1] != 1 and not (torch.equal(k[:, :1].expand_as(k), k) and torch.equal(v[:, :1].expand_as(v), v)):
+            raise NotImplementedError("HIP attention kernel is MQA (one K/V head, as the UNet builds it)")
+        qkv = torch.cat([q.permute(0, 2, 1, 3).reshape(B, N, H * D), k[:, 0], v[:, 0]], dim=-1).to(torch.bfloat16).contiguous()
+        o, _ = ops.mqa_fwd(qkv, B, N, H, D, torch.bfloat16, D ** -0.5)
+        return o.view(B, N, H, D).permute(0, 2, 1, 3).to(v.dtype)

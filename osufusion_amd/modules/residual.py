@@ -1,0 +1,104 @@
+"""HIP-backed mirror of osu_fusion/modules/residual.py: same classes, ctor signatures and state_dict keys.
+
+The nn.Conv1d / nn.GroupNorm / nn.Linear children are parameter containers only (identical names, shapes and
+default init as the reference); their torch forward is never called -- compute goes through the gfx950 kernels.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F  # noqa: N812
+
+from .. import functional as Fn
+from .. import runtime as rt
+
+
+class GlobalContext(nn.Module):
+    """residual.py:14-37.  forward(x: (B,C,L)) -> gate (B, C_out, 1)."""
+
+    def __init__(self, dim_in: int, dim_out: int, reduction: int = 2, dim_min: int = 8) -> None:
+        super().__init__()
+        self.to_k = nn.Conv1d(dim_in, 1, 1)
+        inner_dim = max(dim_min, dim_out // reduction)
+        self.layers = nn.Sequential(
+            nn.Conv1d(dim_in, inner_dim, 1),
+            nn.SiLU(),
+            nn.Conv1d(inner_dim, dim_out, 1),
+            nn.Sigmoid(),
+        )
+        self._c0, self._c2 = Fn.PackCache(), Fn.PackCache()
+
+    def gate_from_rows(self, h: torch.Tensor) -> torch.Tensor:
+        """rows (B, L, C) -> gate fp32 (B, C_out)."""
+        pooled = Fn.GCAPoolFn.apply(h, self.to_k.weight, self.to_k.bias)
+        l0, l2 = self.layers[0], self.layers[2]
+        z = rt.small_linear(pooled, l0.weight, l0.bias, self._c0, "l0")
+        z = rt.small_linear(F.silu(z), l2.weight, l2.bias, self._c2, "l2")
+        return torch.sigmoid(z)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        h = rt.to_rows(x, rt.compute_dtype(self.to_k.weight.dtype))
+        return self.gate_from_rows(h).unsqueeze(-1)
+
+
+class Block(nn.Module):
+    """residual.py:62-88: Conv1d(k3) -> GroupNorm(1, C) -> FiLM -> SiLU."""
+
+    def __init__(self, dim_in: int, dim_out: int, norm: bool = True) -> None:
+        super().__init__()
+        if not norm:
+            raise NotImplementedError("Block(norm=False) is never built by the UNet and has no HIP path")
+        self.proj = nn.Conv1d(dim_in, dim_out, 3, padding=1)
+        self.norm = nn.GroupNorm(1, dim_out)
+        self.activation = nn.SiLU()
+        self._cache = Fn.PackCache()
+
+    def forward_rows(self, x: torch.Tensor, ss: Optional[torch.Tensor]) -> torch.Tensor:
+        return Fn.BlockFn.apply(x, self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias, ss, self._cache)
+
+    def forward(self, x: torch.Tensor, scale_shift: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+        rows = rt.to_rows(x, rt.compute_dtype(self.proj.weight.dtype))
+        ss = None
+        if scale_shift is not None:
+            scale, shift = scale_shift
+            ss = torch.cat([scale.reshape(scale.shape[0], -1), shift.reshape(shift.shape[0], -1)], dim=1).float()
+        return rt.to_logical(self.forward_rows(rows, ss))
+
+
+class ResidualBlock(nn.Module):
+    """residual.py:91-137."""
+
+    def __init__(self, dim_in: int, dim_out: int, dim_time: Optional[int] = None, dim_cond: Optional[int] = None,
+                 use_gca: bool = True) -> None:
+        super().__init__()
+        if not use_gca:
+            raise NotImplementedError("SqueezeExcite (use_gca=False) is never built by the UNet and has no HIP path")
+        self.has_time_cond = dim_time is not None
+        self.has_cond = dim_cond is not None
+        self.mlp = (
+            nn.Sequential(nn.SiLU(), nn.Linear(int(dim_time) + int(dim_cond), dim_out * 2))
+            if dim_time or dim_cond
+            else None
+        )
+        self.block1 = Block(dim_in, dim_out)
+        self.block2 = Block(dim_out, dim_out)
+        self.res_conv = nn.Conv1d(dim_in, dim_out, 1) if dim_in != dim_out else nn.Identity()
+        self.se = GlobalContext(dim_out, dim_out)
+        self._cm, self._cr = Fn.PackCache(), Fn.PackCache()
+
+    def forward_rows(self, x: torch.Tensor, t: Optional[torch.Tensor], c: Optional[torch.Tensor]) -> torch.Tensor:
+        ss = None
+        if self.mlp is not None and (self.has_time_cond or self.has_cond):
+            emb = torch.cat([e for e in (t, c) if e is not None], dim=-1).float()
+            lin = self.mlp[1]
+            ss = rt.small_linear(F.silu(emb), lin.weight, lin.bias, self._cm, "mlp")     # (B, 2C): scale | shift
+        h = self.block1.forward_rows(x, ss)
+        h = self.block2.forward_rows(h, None)
+        gate = self.se.gate_from_rows(h)
+        if isinstance(self.res_conv, nn.Identity):
+            return Fn.GateResFn.apply(h, gate, x)
+        return Fn.GateResConvFn.apply(h, gate, x, self.res_conv.weight, self.res_conv.bias, self._cr)
+
+    def forward(self, x: torch.Tensor, t: Optional[torch.Tensor] = None, c: Optional[torch.Tensor] = None) -> torch.Tensor:
+        rows = rt.to_rows(x, rt.compute_dtype(self.block1.proj.weight.dtype))
+        return rt.to_logical(self.forward_rows(rows, t, c))

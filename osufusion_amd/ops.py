@@ -1,0 +1,308 @@
+"""Raw (non-autograd) wrappers: torch tensors in, one C-ABI kernel launch each.  No fallbacks.
+
+"rows" tensors are channels-last activations: contiguous (B, L, C) or (M, C); only the last dim must be
+contiguous, the row stride may exceed the width (column slices of wider buffers are fine).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _rows(t: torch.Tensor) -> Tuple[int, int, int]:
+    """(M, cols, row stride) of a rows tensor."""
+    assert t.is_cuda, "osufusion_amd kernels run on the GPU only (no CPU fallback)"
+    assert t.stride(-1) == 1, "last dim must be contiguous"
+    cols = t.shape[-1]
+    if t.dim() == 2:
+        return t.shape[0], cols, t.stride(0)
+    assert t.dim() == 3
+    B, Lr = t.shape[0], t.shape[1]
+    ld = t.stride(1)
+    assert t.stride(0) == Lr * ld or B == 1, "batch dim must be densely stacked rows"
+    return B * Lr, cols, ld
+
+
+def dt_of(t: torch.Tensor) -> int:
+    return _DT[t.dtype]
+
+
+def call(name: str, *args) -> None:
+    lib = _lib.load()
+    _lib.check(getattr(lib, name)(*args), name)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GEMMs
+# ---------------------------------------------------------------------------------------------------------
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, taps: int = 1, n_out: Optional[int] = None,
+            lin: Optional[int] = None, lout: Optional[int] = None, stride: int = 1, pad: int = 0, mode: int = 0, act: int = 0,
+            residual: Optional[torch.Tensor] = None, rscale: Optional[torch.Tensor] = None, dact: Optional[torch.Tensor] = None,
+            stats: Optional[torch.Tensor] = None, want_pre: bool = False, out: Optional[torch.Tensor] = None,
+            out_shape: Optional[Tuple[int, ...]] = None):
+    """C = epilogue(sum_t A[rowmap(m,t)] @ W[t].T).  a: rows [Min][K]; w: [taps][N][K] (same dtype).  See gemm.hip."""
+    Min, K, lda = _rows(a)
+    assert w.dtype == a.dtype and w.is_contiguous()
+    w3 = w if w.dim() == 3 else w.unsqueeze(0)
+    assert w3.shape[0] == taps and w3.shape[2] == K, (tuple(w3.shape), taps, K)
+    N = w3.shape[1] if n_out is None else n_out
+    if lin is None:
+        lin = lout = Min                      # plain GEMM: one "sample" of Min rows
+    nb = Min // lin
+    M = nb * lout
+    if out is None:
+        shape = out_shape if out_shape is not None else (M, N)
+        out = torch.empty(shape, dtype=a.dtype, device=a.device)
+    Mo, No, ldc = _rows(out)
+    assert Mo == M and No >= N
+    pre = torch.empty_like(out) if want_pre else None
+    ldr = _rows(residual)[2] if residual is not None else 0
+    ldu = _rows(dact)[2] if dact is not None else 0
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() >= N
+    call("osuf_gemm_nt", dt_of(a), _p(a), lda, _p(w3), K, N * K if taps > 1 else 0, _p(out), ldc, _p(pre), ldc, _p(residual), ldr,
+         _p(dact), ldu, _p(bias), _p(rscale), _p(stats), M, N, K, taps, lin, lout, stride, pad, mode, act, _stream())
+    return (out, pre) if want_pre else out
+
+
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, *, taps: int = 1, lin: Optional[int] = None, lout: Optional[int] = None, stride: int = 1,
+            pad: int = 0, mode: int = 0, n1: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dW[t][n1][n2] = sum_m dY[m][n1] * X[rowmap(m,t)][n2] -> fp32 [taps][N1][N2]."""
+    M, N1, ldy = _rows(dy)
+    Mx, N2, ldx = _rows(x)
+    if n1 is not None:
+        N1 = n1
+    if lin is None:
+        lin = lout = M
+    assert dy.dtype == x.dtype and Mx // lin == M // lout
+    if out is None:
+        out = torch.zeros((taps, N1, N2), dtype=torch.float32, device=dy.device)
+    call("osuf_gemm_tn", dt_of(dy), _p(dy), ldy, _p(x), ldx, _p(out), N2, N1 * N2, M, N1, N2, taps, lin, lout, stride, pad, mode, 0, _stream())
+    return out
+
+
+def colsum(y: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
+    M, N, ld = _rows(y)
+    N = N if n is None else n
+    out = torch.zeros(N, dtype=torch.float32, device=y.device)
+    call("osuf_colsum", dt_of(y), _p(y), ld, M, N, _p(out), _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# norms / gating
+# ---------------------------------------------------------------------------------------------------------
+def gn_finalize(stats: torch.Tensor, count: int) -> torch.Tensor:
+    B = stats.shape[0]
+    mr = torch.empty((B, 2), dtype=torch.float32, device=stats.device)
+    call("osuf_gn_finalize", _p(stats), _p(mr), B, count, _stream())
+    return mr
+
+
+def gn_apply(y: torch.Tensor, mr: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ss: Optional[torch.Tensor], L: int) -> torch.Tensor:
+    M, C, ld = _rows(y)
+    h = torch.empty(y.shape, dtype=y.dtype, device=y.device)
+    call("osuf_gn_apply_fwd", dt_of(y), _p(y), ld, _p(h), C, _p(mr), _p(gamma), _p(beta), _p(ss), M, C, L, _stream())
+    return h
+
+
+def gn_bwd(dh: torch.Tensor, y: torch.Tensor, mr: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ss: Optional[torch.Tensor], L: int):
+    M, C, ldy = _rows(y)
+    B = M // L
+    dev = y.device
+    dy = torch.empty(y.shape, dtype=y.dtype, device=dev)
+    T12 = torch.zeros((B, 2, C), dtype=torch.float32, device=dev)
+    S = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    dss = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if ss is not None else None
+    dgb = torch.zeros((2, C), dtype=torch.float32, device=dev)
+    call("osuf_gn_bwd", dt_of(y), _p(dh), _rows(dh)[2], _p(y), ldy, _p(dy), C, _p(mr), _p(gamma), _p(beta), _p(ss), _p(T12), _p(S),
+         _p(dss), _p(dgb[0]), _p(dgb[1]), M, C, L, _stream())
+    return dy, dgb[0], dgb[1], dss
+
+
+def ln_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    M, C, ld = _rows(x)
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    mr = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    call("osuf_ln_fwd", dt_of(x), _p(x), ld, _p(out), C, _p(mr), _p(gamma), _p(beta), M, C, _stream())
+    return out, mr
+
+
+def ln_bwd(dy: torch.Tensor, x: torch.Tensor, mr: torch.Tensor, gamma: torch.Tensor):
+    M, C, ld = _rows(x)
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    dgb = torch.zeros((2, C), dtype=torch.float32, device=x.device)
+    call("osuf_ln_bwd", dt_of(x), _p(dy), _rows(dy)[2], _p(x), ld, _p(dx), C, _p(mr), _p(gamma), _p(dgb[0]), _p(dgb[1]), M, C, _stream())
+    return dx, dgb[0], dgb[1]
+
+
+def rowdot(h: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], L: int, per_sample: bool = False) -> torch.Tensor:
+    M, C, ld = _rows(h)
+    out = torch.empty(M, dtype=torch.float32, device=h.device)
+    call("osuf_rowdot", dt_of(h), _p(h), ld, _p(w), C if per_sample else 0, _p(bias), _p(out), M, C, L, _stream())
+    return out
+
+
+def softmax_rows_(p: torch.Tensor, B: int, L: int) -> torch.Tensor:
+    call("osuf_softmax_rows", _p(p), B, L, _stream())
+    return p
+
+
+def wcolsum(a: torch.Tensor, bmul: Optional[torch.Tensor], w: Optional[torch.Tensor], B: int, L: int) -> torch.Tensor:
+    M, C, ld = _rows(a)
+    out = torch.zeros((B, C), dtype=torch.float32, device=a.device)
+    call("osuf_wcolsum", dt_of(a), _p(a), ld, _p(bmul), _rows(bmul)[2] if bmul is not None else 0, _p(w), _p(out), B, C, L, _stream())
+    return out
+
+
+def gate_residual(h: torch.Tensor, gate: torch.Tensor, res: torch.Tensor, L: int) -> torch.Tensor:
+    M, C, ld = _rows(h)
+    out = torch.empty(h.shape, dtype=h.dtype, device=h.device)
+    call("osuf_gate_residual", dt_of(h), _p(h), ld, _p(gate), _p(res), _rows(res)[2], _p(out), C, M, C, L, _stream())
+    return out
+
+
+def gca_bwd_apply(dout, h, p, gate, dpooled, sdot, wk, L: int):
+    M, C, ld = _rows(h)
+    dh = torch.empty(h.shape, dtype=h.dtype, device=h.device)
+    dlogit = torch.empty(M, dtype=torch.float32, device=h.device)
+    call("osuf_gca_bwd_apply", dt_of(h), _p(dout), _rows(dout)[2], _p(h), ld, _p(dh), C, _p(p), _p(gate), _p(dpooled), _p(sdot), _p(wk),
+         _p(dlogit), M, C, L, _stream())
+    return dh, dlogit
+
+
+# ---------------------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------------------
+def rope_cast(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, N: int, n_rot: int, n_heads: int, head_dim: int) -> torch.Tensor:
+    M, W, ld = _rows(qkv)
+    out = torch.empty(qkv.shape, dtype=torch.bfloat16, device=qkv.device)
+    call("osuf_rope_cast", dt_of(qkv), _p(qkv), ld, _p(out), W, _p(cos), _p(sin), M, N, n_rot, n_heads, head_dim, _stream())
+    return out
+
+
+def rope_bwd(dqkv32: torch.Tensor, out_dtype: torch.dtype, cos, sin, N: int, n_rot: int, n_heads: int, head_dim: int) -> torch.Tensor:
+    M, W, ld = _rows(dqkv32)
+    out = torch.empty(dqkv32.shape, dtype=out_dtype, device=dqkv32.device)
+    call("osuf_rope_bwd", _DT[out_dtype], _p(dqkv32), ld, _p(out), W, _p(cos), _p(sin), M, N, n_rot, n_heads, head_dim, _stream())
+    return out
+
+
+def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.dtype, scale: float):
+    """qkv: bf16 rows [B*N][(H+2)*D] (q heads | k | v).  Returns o rows [B*N][H*D] and lse2 [B][H][N]."""
+    M, W, ld = _rows(qkv)
+    assert qkv.dtype == torch.bfloat16 and W == (H + 2) * D
+    o = torch.empty((B, N, H * D), dtype=out_dtype, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    base = qkv.data_ptr()
+    call("osuf_mqa_fwd", base, ld, base + 2 * H * D, ld, base + 2 * (H + 1) * D, ld, _p(o), H * D, _DT[out_dtype], _p(lse), B, H, N, D,
+         scale, _stream())
+    return o, lse
+
+
+def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, D: int, scale: float) -> torch.Tensor:
+    """Returns fp32 grads laid out like qkv: [B*N][(H+2)*D]."""
+    M, W, ld = _rows(qkv)
+    assert do.dtype == torch.bfloat16
+    dqkv = torch.empty((B, N, W), dtype=torch.float32, device=qkv.device)
+    delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    base, gbase = qkv.data_ptr(), dqkv.data_ptr()
+    call("osuf_mqa_bwd", base, ld, base + 2 * H * D, ld, base + 2 * (H + 1) * D, ld, _p(o), _rows(o)[2], _DT[o.dtype], _p(do), _rows(do)[2],
+         _p(lse), _p(delta), gbase, W, gbase + 4 * H * D, gbase + 4 * (H + 1) * D, W, B, H, N, D, scale, _stream())
+    return dqkv
+
+
+# ---------------------------------------------------------------------------------------------------------
+# layout / scheduler / optimizer
+# ---------------------------------------------------------------------------------------------------------
+def ncl_to_rows(x: torch.Tensor, dtype: torch.dtype, width: int, kt: int = 1) -> torch.Tensor:
+    """(B, C, L) fp32 contiguous -> rows (B, L, width) [im2col over kt taps when kt > 1]."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.is_cuda
+    B, C, Lx = x.shape
+    out = torch.empty((B, Lx, width), dtype=dtype, device=x.device)
+    call("osuf_ncl_to_rows", _DT[dtype], _p(x), _p(out), width, width, B, C, Lx, kt, _stream())
+    return out
+
+
+def rows_to_ncl(rows: torch.Tensor, C: int) -> torch.Tensor:
+    """rows (B, L, >=C) -> (B, C, L) fp32 contiguous."""
+    B, Lx = rows.shape[0], rows.shape[1]
+    out = torch.empty((B, C, Lx), dtype=torch.float32, device=rows.device)
+    call("osuf_rows_to_ncl", dt_of(rows), _p(rows), _rows(rows)[2], _p(out), B, C, Lx, _stream())
+    return out
+
+
+def copy2d(src: torch.Tensor, dst: torch.Tensor, cols: Optional[int] = None) -> torch.Tensor:
+    M, W, lds = _rows(src)
+    Md, Wd, ldd = _rows(dst)
+    cols = W if cols is None else cols
+    assert M == Md and Wd >= cols
+    call("osuf_copy2d", dt_of(src), _p(src), lds, dt_of(dst), _p(dst), ldd, M, cols, _stream())
+    return dst
+
+
+def cast_rows(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    if src.dtype == dtype:
+        return src
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    return copy2d(src, dst)
+
+
+def add_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    M, W, lda = _rows(a)
+    out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+    call("osuf_add2d", dt_of(a), _p(a), lda, _p(b), _rows(b)[2], _p(out), W, M, W, _stream())
+    return out
+
+
+def axpby_rows(x: torch.Tensor, y: torch.Tensor, ca: torch.Tensor, cb: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(x)
+    call("osuf_axpby_rows", _p(x), _p(y), _p(ca), _p(cb), _p(out), x.shape[0], x[0].numel(), _stream())
+    return out
+
+
+def ddim_step(x: torch.Tensor, cond: torch.Tensor, null: Optional[torch.Tensor], cond_scale: float, coef: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(x)
+    call("osuf_ddim_step", _p(x), _p(cond), _p(null), float(cond_scale), _p(coef), _p(out), x.shape[0], x[0].numel(), _stream())
+    return out
+
+
+def mse(pred: torch.Tensor, target: torch.Tensor, orig_len: Optional[torch.Tensor], want_grad: bool):
+    B, Dc, Lx = pred.shape
+    grad = torch.empty_like(pred) if want_grad else None
+    acc = torch.zeros(1, dtype=torch.float64, device=pred.device)
+    ol = orig_len.to(device=pred.device, dtype=torch.int32).contiguous() if orig_len is not None else None
+    call("osuf_mse", _p(pred), _p(target), _p(ol), _p(grad), _p(acc), B, Dc, Lx, _stream())
+    return acc, grad
+
+
+def sqnorm(flat: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    call("osuf_sqnorm", _p(flat), flat.numel(), _p(out), _stream())
+    return out
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, gscale=None) -> None:
+    call("osuf_adamw", _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, step, _p(gscale), _stream())
+
+
+def clip_coef(sumsq: torch.Tensor, max_norm: float, base: float, coef: torch.Tensor, total_norm: Optional[torch.Tensor]) -> None:
+    call("osuf_clip_coef", _p(sumsq), float(max_norm), float(base), _p(coef), _p(total_norm), _stream())
+
+
+def cast_f32_bf16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    call("osuf_cast_f32_bf16", _p(src), _p(dst), src.numel(), _stream())
+    return dst

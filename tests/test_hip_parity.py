@@ -1,0 +1,367 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIP path vs the oracle / golden vectors, through the C ABI.
+
+Tolerances (relative to the reference tensor's max-abs unless stated):
+  fp32 mode : 1e-3  -- north_star's bound vs the reference's PyTorch-CPU outputs (goldens); most ops land at 1e-5..1e-4,
+                       attention is bf16 inside the reference itself (attention.py:87-101), noise floor ~5e-4.
+  bf16 mode : 3e-2 element-wise on single blocks vs the oracle's bf16 emulation, 2e-2 rel-L2 on whole-UNet outputs.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from osufusion_amd.pattern import param_pattern, synth_inputs, uniform_pm
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import osufusion_amd as oa
+    from osufusion_amd import functional as Fn
+    from osufusion_amd import ops
+    from osufusion_amd.models.diffusion import OsuFusion
+    from osufusion_amd.modules import residual as R
+    from osufusion_amd.modules import unet as U
+
+from oracle import diffusion_oracle as DO
+from oracle import unet_oracle as O
+
+DEV = "cuda"
+B = 2
+
+
+def T(a, dev=DEV):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def relmax(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu() if isinstance(b, torch.Tensor) else torch.from_numpy(np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).abs().max() / (b.abs().max() + 1e-20)).item()
+
+
+def rell2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu() if isinstance(b, torch.Tensor) else torch.from_numpy(np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).norm() / (b.norm() + 1e-20)).item()
+
+
+def load_pattern(module):
+    sd = {k: T(param_pattern(k, tuple(v.shape))) for k, v in module.state_dict().items()}
+    module.load_state_dict(sd, strict=True)
+    return module
+
+
+def G(golden_dir, name):
+    return np.load(golden_dir / f"{name}.npz")
+
+
+# --------------------------------------------------------------------------------------------------------
+# raw kernels vs torch
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mfma_layout_exact_integers(dtype):
+    """A=I-style exactness check with asymmetric integer operands: every MFMA fragment map must be right."""
+    M, N, K = 160, 136, 72
+    a = torch.randint(-3, 4, (M, K), device=DEV).to(dtype)
+    w = torch.randint(-3, 4, (N, K), device=DEV).to(dtype)
+    want = a.double() @ w.double().t()
+    got = ops.gemm_nt(a, w.unsqueeze(0).contiguous(), None)
+    assert torch.equal(got.double(), want)
+    dy = torch.randint(-2, 3, (M, N), device=DEV).to(dtype)
+    gw = ops.gemm_tn(dy, a)[0]
+    assert torch.equal(gw.double(), dy.double().t() @ a.double())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("kind,k,L", [("same", 3, 96), ("same", 1, 64), ("same", 7, 40), ("same", 15, 200), ("down", 3, 96), ("up", 3, 56),
+                                      ("same", 3, 8), ("down", 3, 300)])
+def test_conv_fn_forward_backward(dtype, tol, kind, k, L):
+    Cin, Cout = 48, 72
+    x = torch.randn(B, Cin, L, device=DEV)
+    w = (torch.randn(Cout, Cin, k, device=DEV) / (Cin * k) ** 0.5).requires_grad_()
+    b = torch.randn(Cout, device=DEV).requires_grad_()
+    xq = x.to(dtype).float().requires_grad_()
+    wq = w.detach().to(dtype).float().requires_grad_()
+    if kind == "same":
+        ref = F.conv1d(xq, wq, b, padding=k // 2)
+    elif kind == "down":
+        ref = F.conv1d(F.pad(xq, (0, 1), mode="reflect"), wq, b, stride=2)
+    else:
+        ref = F.conv1d(F.interpolate(xq, scale_factor=2.0, mode="nearest"), wq, b, padding=1)
+    rows = x.permute(0, 2, 1).contiguous().to(dtype).requires_grad_()
+    out = Fn.ConvFn.apply(rows, w, b, Fn.PackCache(), kind)
+    assert relmax(out.float().permute(0, 2, 1), ref) < tol
+    g = torch.randn_like(ref)
+    gq = g.to(dtype).float()
+    ref.backward(gq)
+    out.backward(g.permute(0, 2, 1).contiguous().to(dtype))
+    assert relmax(rows.grad.float().permute(0, 2, 1), xq.grad) < tol
+    assert relmax(w.grad, wq.grad) < tol
+    assert relmax(b.grad, gq.sum((0, 2))) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("film", [False, True])
+def test_block_fn(dtype, tol, film):
+    Cin, C, L = 40, 64, 136
+    x = torch.randn(B, Cin, L, device=DEV).to(dtype).float()
+    blk = load_pattern(R.Block(Cin, C).to(DEV))
+    ss = (torch.randn(B, 2 * C, device=DEV) * 0.3).requires_grad_() if film else None
+    nm = O.Numerics("bf16" if dtype == torch.bfloat16 else "fp32")
+    p = {"m." + k: v.detach().cpu().clone().requires_grad_() for k, v in blk.state_dict().items()}
+    xr = x.cpu().clone().requires_grad_()
+    ssr = ss.detach().cpu().clone().requires_grad_() if film else None
+    ref = O.block(p, "m", xr, (ssr[:, :C, None], ssr[:, C:, None]) if film else None, nm)
+    rows = x.permute(0, 2, 1).contiguous().to(dtype).requires_grad_()
+    out = blk.forward_rows(rows, ss)
+    assert relmax(out.float().permute(0, 2, 1), ref) < tol
+    g = torch.randn(B, C, L).to(dtype).float()
+    ref.backward(g)
+    out.backward(g.to(DEV).permute(0, 2, 1).contiguous().to(dtype))
+    assert relmax(rows.grad.float().permute(0, 2, 1), xr.grad) < 3 * tol
+    assert relmax(blk.proj.weight.grad, p["m.proj.weight"].grad) < 3 * tol
+    assert relmax(blk.proj.bias.grad, p["m.proj.bias"].grad) < 3 * tol
+    assert relmax(blk.norm.weight.grad, p["m.norm.weight"].grad) < 3 * tol
+    assert relmax(blk.norm.bias.grad, p["m.norm.bias"].grad) < 3 * tol
+    if film:
+        assert relmax(ss.grad, ssr.grad) < 3 * tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 2e-2)])
+def test_global_context_and_gate(dtype, tol):
+    C, L = 48, 200
+    h = torch.randn(B, C, L, device=DEV).to(dtype).float()
+    gc = load_pattern(R.GlobalContext(C, C).to(DEV))
+    p = {"m." + k: v.detach().cpu().clone().requires_grad_() for k, v in gc.state_dict().items()}
+    hr = h.cpu().clone().requires_grad_()
+    ref_gate = O.global_context(p, "m", hr, O.Numerics("fp32"))
+    res = torch.randn(B, C, L).to(dtype).float()
+    ref = hr * ref_gate + res
+    rows = h.permute(0, 2, 1).contiguous().to(dtype).requires_grad_()
+    gate = gc.gate_from_rows(rows)
+    assert relmax(gate, ref_gate[..., 0]) < tol
+    out = Fn.GateResFn.apply(rows, gate, res.to(DEV).permute(0, 2, 1).contiguous().to(dtype))
+    assert relmax(out.float().permute(0, 2, 1), ref) < tol
+    g = torch.randn(B, C, L).to(dtype).float()
+    ref.backward(g)
+    out.backward(g.to(DEV).permute(0, 2, 1).contiguous().to(dtype))
+    assert relmax(rows.grad.float().permute(0, 2, 1), hr.grad) < 3 * tol
+    for k in ("to_k.weight", "layers.0.weight", "layers.0.bias", "layers.2.weight", "layers.2.bias"):
+        assert relmax(dict(gc.named_parameters())[k].grad, p["m." + k].grad) < 5 * tol, k
+
+
+@pytest.mark.parametrize("N", [8, 64, 200, 512])
+def test_mqa_flash_vs_sdpa(N):
+    H, D = 4, 64
+    qkv = torch.randn(B, N, (H + 2) * D, device=DEV).to(torch.bfloat16)
+    o, lse = ops.mqa_fwd(qkv, B, N, H, D, torch.bfloat16, D ** -0.5)
+    q = qkv[..., : H * D].view(B, N, H, D).permute(0, 2, 1, 3).float().cpu()
+    k = qkv[..., H * D: (H + 1) * D].float().cpu()[:, None].expand(B, H, N, D)
+    v = qkv[..., (H + 1) * D:].float().cpu()[:, None].expand(B, H, N, D)
+    s = (q @ k.transpose(-1, -2)) * D ** -0.5
+    ref = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B, N, H * D)
+    assert relmax(o.float(), ref) < 1.5e-2                          # bf16 P and bf16 output rounding
+    assert rell2(o.float(), ref) < 5e-3
+    ref_lse2 = torch.logsumexp(s, -1) / np.log(2.0)
+    assert (lse.cpu() - ref_lse2).abs().max() < 2e-3
+    # backward vs autograd of the fp32 formula
+    qkv32 = qkv.float().cpu().requires_grad_()
+    q2 = qkv32[..., : H * D].view(B, N, H, D).permute(0, 2, 1, 3)
+    k2 = qkv32[..., H * D: (H + 1) * D][:, None]
+    v2 = qkv32[..., (H + 1) * D:][:, None]
+    o2 = (((q2 @ k2.transpose(-1, -2)) * D ** -0.5).softmax(-1) @ v2).permute(0, 2, 1, 3).reshape(B, N, H * D)
+    do = torch.randn(B, N, H * D).to(torch.bfloat16)
+    o2.backward(do.float())
+    dqkv = ops.mqa_bwd(qkv, o, do.to(DEV), lse, B, N, H, D, D ** -0.5)
+    assert rell2(dqkv, qkv32.grad) < 1e-2
+    assert relmax(dqkv, qkv32.grad) < 3e-2
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 3e-2)])
+def test_transformer_block_vs_oracle(dtype, tol):
+    C, N = 96, 136
+    cfg = O.UNetConfig(dim_h=C, attn_dim_head=64, attn_heads=4, attn_kv_heads=1)
+    blk = load_pattern(U.TransformerBlock(C, attn_dim_head=64, attn_heads=4, attn_kv_heads=1, attn_context_len=256).to(DEV))
+    p = {"m." + k: v.detach().cpu().clone().requires_grad_() for k, v in blk.state_dict().items()}
+    x = torch.randn(B, C, N).to(dtype).float()
+    xr = x.clone().requires_grad_()
+    ref = O.transformer_block(p, "m", xr, cfg, 256, O.Numerics("bf16" if dtype == torch.bfloat16 else "fp32"))
+    rows = x.to(DEV).permute(0, 2, 1).contiguous().to(dtype).requires_grad_()
+    out = blk.forward_rows(rows)
+    assert relmax(out.float().permute(0, 2, 1), ref) < tol
+    g = torch.randn(B, C, N).to(dtype).float()
+    ref.backward(g)
+    out.backward(g.to(DEV).permute(0, 2, 1).contiguous().to(dtype))
+    gtol = 2e-2 if dtype == torch.float32 else 6e-2                   # SDPA backward is bf16 on both sides
+    assert rell2(rows.grad.float().permute(0, 2, 1), xr.grad) < gtol
+    for k, v in blk.named_parameters():
+        assert rell2(v.grad, p["m." + k].grad) < gtol, k
+
+
+def test_scheduler_and_optimizer_kernels():
+    x = torch.randn(4, 6, 100, device=DEV)
+    n = torch.randn_like(x)
+    t = torch.tensor([0, 17, 500, 999], device=DEV)
+    from osufusion_amd.models.diffusion import DDIMSchedule
+    sch = DDIMSchedule()
+    acp = DO.ddim_alphas_cumprod()
+    assert torch.allclose(sch.add_noise(x, n, t).cpu(), DO.add_noise(x.cpu(), n.cpu(), t.cpu(), acp), atol=1e-6)
+    sch.set_timesteps(50)
+    assert sch.timesteps.tolist() == DO.ddim_timesteps(50).tolist()
+    for tt in (980, 500, 0):
+        coef = torch.tensor([sch.step_coefficients(tt)] * 4, dtype=torch.float32, device=DEV)
+        null = torch.randn_like(x)
+        got = ops.ddim_step(x, n, null, 2.0, coef)
+        eps = null.cpu() + (n.cpu() - null.cpu()) * 2.0
+        assert torch.allclose(got.cpu(), DO.ddim_step(eps, tt, x.cpu(), acp, 50), atol=2e-6)
+    # AdamW vs torch.optim.AdamW, 3 steps, odd length
+    nel = 1027
+    p0 = torch.randn(nel, device=DEV)
+    pt = p0.clone().requires_grad_()
+    opt = torch.optim.AdamW([pt], lr=1e-3, weight_decay=1e-2)
+    p, m, v = p0.clone(), torch.zeros(nel, device=DEV), torch.zeros(nel, device=DEV)
+    for step in range(1, 4):
+        g = torch.randn(nel, device=DEV)
+        pt.grad = g.clone()
+        opt.step()
+        ops.adamw(p, g, m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step)
+    assert torch.allclose(p, pt.detach(), atol=1e-6)
+    acc = torch.zeros(1, dtype=torch.float64, device=DEV)
+    ops.sqnorm(g, acc)
+    assert abs(acc.item() - (g.double() ** 2).sum().item()) < 1e-6 * acc.item()
+    pred, tgt = torch.randn(3, 6, 50, device=DEV), torch.randn(3, 6, 50, device=DEV)
+    ol = torch.tensor([50, 20, 35])
+    acc, grad = ops.mse(pred, tgt, ol, True)
+    mask = (torch.arange(50)[None] < ol[:, None]).float()[:, None].to(DEV)
+    assert abs(acc.item() - (((pred - tgt) ** 2) * mask).sum().item()) < 1e-3
+
+
+# --------------------------------------------------------------------------------------------------------
+# modules vs golden vectors (fp32 mode; the reference's own outputs)
+# --------------------------------------------------------------------------------------------------------
+TOL = 1e-3
+
+
+def test_modules_vs_golden(golden_dir):
+    with oa.forced_compute_dtype(torch.float32):
+        x = T(uniform_pm("mod/x48", (B, 48, 96), 1.0))
+        t = T(uniform_pm("mod/t", (B, 64), 1.0))
+        c = T(uniform_pm("mod/c", (B, 64), 1.0))
+        g = G(golden_dir, "mod_block")
+        m = load_pattern(R.Block(48, 80).to(DEV))
+        ss = (T(uniform_pm("mod/scale", (B, 80, 1), 0.5)), T(uniform_pm("mod/shift", (B, 80, 1), 0.5)))
+        assert relmax(m(x), g["y_plain"]) < TOL
+        assert relmax(m(x, scale_shift=ss), g["y_film"]) < TOL
+        m = load_pattern(R.GlobalContext(48, 48).to(DEV))
+        assert relmax(m(x), G(golden_dir, "mod_global_context")["y"]) < TOL
+        m = load_pattern(R.ResidualBlock(48, 80, 64, 64).to(DEV))
+        assert relmax(m(x, t, c), G(golden_dir, "mod_resblock_film")["y"]) < TOL
+        m = load_pattern(R.ResidualBlock(48, 48, None, None).to(DEV))
+        assert relmax(m(x), G(golden_dir, "mod_resblock_plain")["y"]) < TOL
+        m = load_pattern(U.Downsample(48, 80).to(DEV))
+        assert relmax(m(x), G(golden_dir, "mod_downsample")["y"]) < TOL
+        m = load_pattern(U.Upsample(48, 80).to(DEV))
+        assert relmax(m(x), G(golden_dir, "mod_upsample")["y"]) < TOL
+        m = load_pattern(U.Parallel(torch.nn.Conv1d(48, 80, 3, padding=1), torch.nn.Conv1d(48, 80, 1)).to(DEV))
+        assert relmax(m(x), G(golden_dir, "mod_parallel")["y"]) < TOL
+        m = load_pattern(U.CrossEmbedLayer(96, 128, (3, 7, 15)).to(DEV))
+        assert relmax(m(T(uniform_pm("mod/xa", (B, 96, 64), 1.0))), G(golden_dir, "mod_cross_embed")["y"]) < TOL
+        m = load_pattern(U.CrossEmbedLayer(6, 128, (3, 7, 15)).to(DEV))
+        assert relmax(m(T(uniform_pm("mod/x6", (B, 6, 64), 1.0))), G(golden_dir, "mod_cross_embed6")["y"]) < TOL
+        m = U.SinusoidalPositionEmbedding(128)
+        assert relmax(m(torch.tensor([0, 1, 17, 500, 999], device=DEV)), G(golden_dir, "mod_sinusoidal")["y"]) < 1e-4
+        m = load_pattern(U.Attention(96, 64, 4, 1, context_len=256).to(DEV))
+        assert relmax(m(T(uniform_pm("mod/xt", (B, 128, 96), 1.0))), G(golden_dir, "mod_attention")["y"]) < TOL
+        m = load_pattern(U.TransformerBlock(96, attn_dim_head=64, attn_heads=4, attn_kv_heads=1, attn_context_len=256).to(DEV))
+        assert relmax(m(T(uniform_pm("mod/xc", (B, 96, 128), 1.0))), G(golden_dir, "mod_transformer")["y"]) < TOL
+        te, ce = T(uniform_pm("mod/te", (B, 64), 1.0)), T(uniform_pm("mod/ce", (B, 64), 1.0))
+        xb = T(uniform_pm("mod/xb", (B, 64, 64), 1.0))
+        for name, li, down, xin, dout in (("mod_unetblock_down", 0, True, xb, 96), ("mod_unetblock_down_last", 1, True, xb, 96),
+                                          ("mod_unetblock_up", 0, False, T(uniform_pm("mod/xu", (B, 112, 64), 1.0)), 48)):
+            m = load_pattern(U.UNetBlock(64, dout, 64, 64, li, 2, 1, down, 64, 2, 1, 128).to(DEV))
+            y, s = m(xin, te, ce)
+            gg = G(golden_dir, name)
+            assert relmax(y, gg["y"]) < TOL, name
+            assert relmax(s, gg["skip"]) < TOL, name
+        m = load_pattern(U.AudioEncoder(96, 96, dim_h_mult=(1, 2), num_layer_blocks=(1, 1), cross_embed_kernel_sizes=(3, 7, 15),
+                                        attn_dim_head=64, attn_heads=2, attn_kv_heads=1).to(DEV))
+        assert relmax(m(T(uniform_pm("mod/xae", (B, 96, 64), 1.0))), G(golden_dir, "mod_audio_encoder")["y"]) < TOL
+
+
+def test_rope_and_attend_modules_vs_golden(golden_dir):
+    from osufusion_amd.modules.attention import RotaryPositionEmbedding
+    for n, sb in ((512, 512), (520, 256)):
+        g = G(golden_dir, f"mod_rope_{n}_{sb}")
+        r = RotaryPositionEmbedding(64, scale_base=sb)
+        q, k = T(uniform_pm(f"mod/ropeq{n}", (1, 2, n, 64), 1.0)), T(uniform_pm(f"mod/ropek{n}", (1, 2, n, 64), 1.0))
+        qo, ko = r(q, k)
+        assert relmax(qo, g["q"]) < 5e-3 and relmax(ko, g["k"]) < 5e-3       # outputs are bf16 (the next op's cast)
+
+
+def _build_model(case, golden_dir):
+    meta = json.loads((golden_dir / "unet_cases.json").read_text())[case]
+    cfgd = {k: (tuple(v) if isinstance(v, list) else v) for k, v in meta["cfg"].items()}
+    kw = {k: v for k, v in cfgd.items() if not k.startswith("dim_in_")}
+    model = OsuFusion(kw.pop("dim_h"), **kw).to(DEV)
+    load_pattern(model.unet)
+    return meta, cfgd, model
+
+
+@pytest.mark.parametrize("case", ["unet_tiny", "unet_mid"])
+def test_unet_vs_golden_fp32(golden_dir, case):
+    meta, cfgd, model = _build_model(case, golden_dir)
+    net = model.unet
+    g = G(golden_dir, case)
+    x, a, c, t, noise = (T(v) for v in synth_inputs(case, meta["B"], meta["L"]))
+    with oa.forced_compute_dtype(torch.float32):
+        with torch.no_grad():
+            assert rell2(net(x, a, t, c, cond_drop_prob=0.0), g["y_cond"]) < TOL
+            assert rell2(net(x, a, t, c, cond_drop_prob=1.0), g["y_null"]) < TOL
+            Lo = meta["L_odd"]
+            assert rell2(net(x[..., :Lo].contiguous(), a[..., :Lo].contiguous(), t, c), g["y_odd"]) < TOL
+        loss = model.loss_with(x, a, c, noise, t, cond_drop_prob=0.0)
+        assert abs(loss.item() - float(g["loss"])) < TOL * abs(float(g["loss"]))
+        loss.backward()
+    names = meta["param_names"]
+    params = dict(net.named_parameters())
+    gn = np.array([params[k].grad.norm().item() for k in names])
+    ref = g["grad_norms"]
+    rel = np.abs(gn - ref) / (ref + 1e-3 * ref.max())
+    assert rel.max() < 2e-2, f"grad-norm mismatch {rel.max():.3e} at {names[int(rel.argmax())]}"
+    for key in g.files:
+        if key.startswith("g/"):
+            got = params[key[2:]].grad.flatten()[:24]
+            assert relmax(got, g[key]) < 2e-2, key
+
+
+@pytest.mark.parametrize("case", ["unet_tiny", "unet_mid"])
+def test_unet_bf16_vs_oracle_emulation(golden_dir, case):
+    meta, cfgd, model = _build_model(case, golden_dir)
+    net = model.unet
+    cfg = O.UNetConfig(**cfgd)
+    p = O.make_params(cfg)
+    x, a, c, t, noise = (torch.from_numpy(v) for v in synth_inputs(case, meta["B"], meta["L"]))
+    with torch.no_grad():
+        ref16 = O.unet_forward(p, cfg, x, a, t, c, mode="bf16")
+        ref32 = O.unet_forward(p, cfg, x, a, t, c, mode="fp32")
+    with oa.forced_compute_dtype(torch.bfloat16), torch.no_grad():
+        got = net(x.to(DEV), a.to(DEV), t.to(DEV), c.to(DEV))
+    e16, e32, floor = rell2(got, ref16), rell2(got, ref32), rell2(ref16, ref32)
+    print(f"{case}: bf16 HIP vs oracle-bf16 {e16:.3e}; vs oracle-fp32 {e32:.3e}; oracle bf16-vs-fp32 {floor:.3e}")
+    assert e16 < 2e-2
+    assert e32 < 3 * floor + 1e-2
+
+
+def test_sampler_vs_oracle(golden_dir):
+    meta, cfgd, model = _build_model("unet_tiny", golden_dir)
+    cfg = O.UNetConfig(**cfgd)
+    p = {"unet." + k: v for k, v in O.make_params(cfg).items()}
+    model.sampling_timesteps = 5
+    x, a, c, t, noise = (torch.from_numpy(v) for v in synth_inputs("sampler", 2, 256))
+    for cs in (1.0, 2.0):
+        ref = DO.sample(p, cfg, a, c, noise.clone(), sampling_steps=5, cond_scale=cs)
+        with oa.forced_compute_dtype(torch.float32):
+            got = model.sample(a.to(DEV), c.to(DEV), noise.to(DEV), cond_scale=cs)
+        assert rell2(got, ref) < 5e-3, cs
