@@ -39,7 +39,8 @@ def param_pattern(name: str, shape: Tuple[int, ...]) -> np.ndarray:
 
     * norm weights      -> 1 + U(-0.2, 0.2)
     * biases, null_cond -> U(-0.1, 0.1)  (null_cond U(-1, 1))
-    * conv / linear     -> U(-a, a), a = sqrt(3 / fan_in)  (unit-gain)
+    * conv / linear     -> U(-a, a), a = 1 / sqrt(fan_in)  (the bound torch's default Conv1d/Linear init uses,
+                           i.e. the reference's own initialisation scale)
     final_conv is *not* zero here: the reference zero-inits it (unet.py:354), which makes
     every other gradient exactly zero and a backward parity test vacuous.
     """
@@ -53,7 +54,7 @@ def param_pattern(name: str, shape: Tuple[int, ...]) -> np.ndarray:
     if leaf == "bias":
         return uniform_pm(name, shape, 0.1)
     fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else int(shape[0])
-    return uniform_pm(name, shape, float(np.sqrt(3.0 / max(fan_in, 1))))
+    return uniform_pm(name, shape, float(np.sqrt(1.0 / max(fan_in, 1))))
 
 
 def fill_state_dict(shapes: Iterable[Tuple[str, Tuple[int, ...]]]) -> Dict[str, np.ndarray]:
