@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoise-steps/sec of one full train step (forward + backward + gradient all-reduce + clip + AdamW)
+of the full OsuFusion UNet (dim_h=256, 343.5 M parameters) at per-GPU batch 32, L=4096, bf16 compute -- BASELINE.json
+configs[1] (N=1) / configs[2] (N>1, weak scaling: global batch 32*N, one process per GPU, RCCL over xGMI).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Shape-mapping note printed with every result: the reference UNet takes audio as (B, 96, L) with the
+same L as the map sequence (models/diffusion.py:86); BASELINE's "C=256" is dim_h=256 and "audio-ctx=1024x128" has no literal
+counterpart (no cross-attention: the audio is encoded to (B, 1024, L/8) and concatenated at the bottleneck, unet.py:483,500).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+DIM_H, BATCH, LENGTH, HEADS, HEAD_DIM = 256, 32, 4096, 16, 64
+STEP_TFLOP = 125.1                      # 3 x 1,303 GFLOP/sample x 32 (recompute not counted)
+
+
+def synth_batch(rank: int, device, batch: int, length: int):
+    """SURVEY section 8d synthetic inputs, generated once and resident in HBM before the timed region."""
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = (torch.randn(batch, 6, length, generator=g) * 0.5).clamp_(-1, 1)
+    a = torch.randn(batch, 96, length, generator=g) * 3 - 10
+    c = torch.rand(batch, 5, generator=g) * 2 - 1
+    t = torch.randint(0, 1000, (batch,), generator=g)
+    noise = torch.randn(batch, 6, length, generator=g)
+    return tuple(v.to(device) for v in (x, a, c, noise, t))
+
+
+def build_model(device, dim_h: int):
+    from osufusion_amd.models.diffusion import OsuFusion
+    torch.manual_seed(0)                                   # identical replicas on every rank
+    model = OsuFusion(dim_h)
+    with torch.no_grad():                                  # the reference zero-inits final_conv (unet.py:354): every other
+        model.unet.final_conv.weight.normal_(0.0, 0.02)    # gradient would be exactly zero -- use a live head instead
+    return model.to(device)
+
+
+def cpu_baseline(model, length: int, threads: int):
+    """The oracle (CPU restatement of the reference, pinned to its golden vectors) on this box's host cores: one fwd+bwd
+    of the same full-size model at B=1, L=length, fp32 params + bf16 SDPA exactly as the reference computes on CPU."""
+    from oracle import diffusion_oracle as DO
+    from oracle import unet_oracle as O
+    torch.set_num_threads(threads)
+    cfg = O.UNetConfig(dim_h=DIM_H)
+    p = {k: v.detach().float().cpu().clone().requires_grad_() for k, v in model.state_dict().items()}
+    x, a, c, noise, t = synth_batch(0, "cpu", 1, length)
+    t0 = time.perf_counter()
+    loss = DO.training_loss(p, cfg, x, a, c, noise, t, cond_drop_prob=0.0)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return dict(value=1.0 / (BATCH * dt), unit="denoise-steps/sec (B=32, linear extrapolation from B=1)", cores=threads, kind="port",
+                sample=f"1 fwd+bwd of the full UNet at B=1, L={length} in {dt:.1f} s (oracle/, fp32 + bf16 SDPA)")
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (the metric is defined at 32)")
+    ap.add_argument("--length", type=int, default=LENGTH)
+    ap.add_argument("--dim-h", type=int, default=DIM_H)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)      # "nccl" is RCCL on ROCm
+
+    from osufusion_amd import ops
+    from osufusion_amd.train import Trainer
+
+    model = build_model(device, args.dim_h)
+    trainer = Trainer(model, lr=1e-4, weight_decay=1e-2, clip_grad_norm=1.0, compute_dtype=torch.bfloat16)
+    x, a, c, noise, t = synth_batch(rank, device, args.batch, args.length)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(x, a, c, noise, t)
+    sync()
+    prof = ops.KernelTimer(["osuf_mqa_fwd", "osuf_mqa_bwd_dq", "osuf_mqa_bwd_dkv"])
+    ops.set_kernel_timer(prof)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, gnorm = trainer.step(x, a, c, noise, t)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        full = (args.batch, args.length, args.dim_h) == (BATCH, LENGTH, DIM_H)
+        value = world * args.steps / elapsed * (args.batch / BATCH)
+        # roofline of the dominant kernel: algorithmic FLOPs per launch / mean launch duration (HIP events, timed region)
+        stats = prof.summary()
+        dom = max(stats, key=lambda k: stats[k]["total_ms"]) if stats else None
+        roof = None
+        if dom is not None:
+            # per launch: forward 4*B*H*N^2*D; dQ kernel 3 of the 5 backward products = 6*B*H*N^2*D; dK/dV kernel 4 = 8*...
+            per = {"osuf_mqa_fwd": 4.0, "osuf_mqa_bwd_dq": 6.0, "osuf_mqa_bwd_dkv": 8.0}[dom]
+            tf = sum(per * args.batch * HEADS * n * n * HEAD_DIM for n in stats[dom]["sizes"]) / 1e12
+            ach = tf / (stats[dom]["total_ms"] / 1e3)
+            roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None, launches=stats[dom]["launches"],
+                        mean_launch_ms=round(stats[dom]["total_ms"] / stats[dom]["launches"], 3),
+                        step_frac_of_peak=round(STEP_TFLOP / (ms / 1e3) / MFMA_BF16_PEAK_TFLOPS, 4) if full else None,
+                        all_kernels_ms_per_step={k: round(v["total_ms"] / args.steps, 2) for k, v in stats.items()})
+        out = {
+            "metric": "denoise-steps/sec (train fwd+bwd) at B=32 L=4096", "value": round(value, 4), "unit": "steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (SURVEY 8d shapes; random-init weights, live final_conv)",
+            "config": {"workload": f"full OsuFusion UNet dim_h={args.dim_h} (343.5M params) train step: fwd+bwd+grad-norm+clip+AdamW"
+                                   f"{'+RCCL all-reduce' if world > 1 else ''}, per-GPU batch {args.batch}, L={args.length}, x (B,6,L), "
+                                   f"audio (B,96,L) [BASELINE 'audio-ctx=1024x128' maps to the (B,1024,L/8) bottleneck code]",
+                       "global_batch": args.batch * world, "seq_len": args.length, "parallelism": f"dp{world}"},
+            "loss": round(loss.item(), 5), "grad_norm": round(gnorm.item(), 4),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, args.length, args.cpu_threads or (os.cpu_count() or 1))
+            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

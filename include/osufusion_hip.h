@@ -90,9 +90,14 @@ int osuf_rope_bwd(int dtype, const float* in, long ld_in, void* out, long ld_out
  * q/k/v/dout are bf16; o is written bf16-rounded in o_dtype; lse2 = log2-domain logsumexp [B][H][N]. */
 int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
                  float* lse2, int B, int H, int N, int head_dim, float scale, hipStream_t stream);
-int osuf_mqa_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* o, long ldo, int o_dtype,
-                 const void* dout, long lddo, const float* lse2, float* delta, float* dq, long lddq, float* dk, float* dv,
-                 long lddk, int B, int H, int N, int head_dim, float scale, hipStream_t stream);
+int osuf_attn_delta(const void* dout, long lddo, const void* o, long ldo, int o_dtype, float* delta, int B, int H, int N,
+                    int head_dim, hipStream_t stream);
+int osuf_mqa_bwd_dq(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
+                    const float* lse2, const float* delta, float* dq, long lddq, int B, int H, int N, int head_dim, float scale,
+                    hipStream_t stream);
+int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
+                     const float* lse2, const float* delta, float* dk, float* dv, long lddk, int B, int H, int N, int head_dim,
+                     float scale, hipStream_t stream);
 
 /* ---- layout / scheduler / optimizer (elementwise.hip) ----------------------------------------------------------
  * replaces: the (B,C,L) <-> (B,L,C) rearranges (modules/unet.py:180,183) at the model boundary, torch.cat (unet.py:500,

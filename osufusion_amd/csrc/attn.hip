@@ -517,25 +517,55 @@ extern "C" int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, co
   return osuf_launch_status();
 }
 
-// delta: [B][H][N] fp32 scratch (written here).  dq: fp32 [B*N][lddq]; dk, dv: fp32 [B*N][lddk]
-extern "C" int osuf_mqa_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* o, long ldo, int o_dtype,
-                            const void* dout, long lddo, const float* lse2, float* delta, float* dq, long lddq, float* dk, float* dv,
-                            long lddk, int B, int H, int N, int head_dim, float scale, hipStream_t stream) {
+static int fill_bwd_args(AttnArgs& a, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
+                         const float* lse2, const float* delta, int B, int H, int N, int head_dim, float scale) {
   if (head_dim != D) return OSUF_EUNSUPPORTED;
-  if (B <= 0 || H <= 0 || N <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8 || lddq % 4 || lddk % 4) return OSUF_EINVAL;
-  if (!al16(q) || !al16(k) || !al16(v) || !al16(o) || !al16(dout) || !al16(dq) || !al16(dk) || !al16(dv)) return OSUF_EINVAL;
+  if (B <= 0 || H <= 0 || N <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || lddo % 8) return OSUF_EINVAL;
+  if (!al16(q) || !al16(k) || !al16(v) || !al16(dout)) return OSUF_EINVAL;
+  a = AttnArgs{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
+  a.lse2 = const_cast<float*>(lse2); a.dout = (const bf16_t*)dout; a.lddo = lddo; a.delta = delta;
+  a.B = B; a.H = H; a.N = N; a.scale = scale;
+  return OSUF_OK;
+}
+
+// delta[b][h][n] = sum_d dO * O   (o: bf16 or f32 storage of the forward output)
+extern "C" int osuf_attn_delta(const void* dout, long lddo, const void* o, long ldo, int o_dtype, float* delta, int B, int H, int N,
+                               int head_dim, hipStream_t stream) {
+  if (head_dim != D) return OSUF_EUNSUPPORTED;
+  if (B <= 0 || H <= 0 || N <= 0 || ldo % 8 || lddo % 8 || !al16(o) || !al16(dout)) return OSUF_EINVAL;
   const long tot = (long)B * N * H * 8;
   if (o_dtype == OSUF_DT_F32) {
     hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(ew_grid(tot)), dim3(256), 0, stream, (const bf16_t*)dout, lddo, (const float*)o, ldo, delta, B, H, N);
   } else {
     hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3(ew_grid(tot)), dim3(256), 0, stream, (const bf16_t*)dout, lddo, (const bf16_t*)o, ldo, delta, B, H, N);
   }
-  AttnArgs a = {};
-  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
-  a.lse2 = const_cast<float*>(lse2); a.dout = (const bf16_t*)dout; a.lddo = lddo; a.delta = delta;
-  a.dq = dq; a.lddq = lddq; a.dk = dk; a.dv = dv; a.lddk = lddk; a.B = B; a.H = H; a.N = N; a.scale = scale;
+  return osuf_launch_status();
+}
+
+// dq: fp32 [B*N][lddq], head h at columns h*64
+extern "C" int osuf_mqa_bwd_dq(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
+                               const float* lse2, const float* delta, float* dq, long lddq, int B, int H, int N, int head_dim, float scale,
+                               hipStream_t stream) {
+  AttnArgs a;
+  int rc = fill_bwd_args(a, q, ldq, k, ldk, v, ldv, dout, lddo, lse2, delta, B, H, N, head_dim, scale);
+  if (rc) return rc;
+  if (lddq % 4 || !al16(dq)) return OSUF_EINVAL;
+  a.dq = dq; a.lddq = lddq;
   const int nvb = ((N + 31) / 32) * H;
   hipLaunchKernelGGL(mqa_bwd_dq_kernel, dim3((nvb + 7) / 8, B), dim3(512), 32768, stream, a);
+  return osuf_launch_status();
+}
+
+// dk, dv: fp32 [B*N][lddk]
+extern "C" int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
+                                const float* lse2, const float* delta, float* dk, float* dv, long lddk, int B, int H, int N, int head_dim,
+                                float scale, hipStream_t stream) {
+  AttnArgs a;
+  int rc = fill_bwd_args(a, q, ldq, k, ldk, v, ldv, dout, lddo, lse2, delta, B, H, N, head_dim, scale);
+  if (rc) return rc;
+  if (lddk % 4 || !al16(dk) || !al16(dv)) return OSUF_EINVAL;
+  a.dk = dk; a.dv = dv; a.lddk = lddk;
   hipLaunchKernelGGL(mqa_bwd_dkv_kernel, dim3((N + 255) / 256, B), dim3(512), 2 * (4096 + 4096 + 256), stream, a);
   return osuf_launch_status();
 }

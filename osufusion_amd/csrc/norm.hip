@@ -291,22 +291,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, con
       }
     }
   }
-  // reduce dgamma/dbeta partials: lanes with equal gl across the wave (xor over the row-group bits), then atomics
+  // reduce dgamma/dbeta partials: lanes with equal gl across the wave (xor over the row-group bits), then across the
+  // block's 4 waves through LDS, then ONE atomic per channel per block (the grid is capped at 256 blocks by the host)
   for (int o = G; o < 64; o <<= 1) {
 #pragma unroll
     for (int j = 0; j < kMaxCh; ++j)
 #pragma unroll
       for (int e = 0; e < 8; ++e) { ag[j][e] += __shfl_xor(ag[j][e], o, 64); ab[j][e] += __shfl_xor(ab[j][e], o, 64); }
   }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);                 // [4 waves][2][C]
+  const int wave = threadIdx.x >> 6;
   if (gr == 0) {
 #pragma unroll
     for (int j = 0; j < kMaxCh; ++j) {
       const int ch = gl + j * G;
       if (ch < chunks) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { atomic_add_f32(dgamma + ch * 8 + e, ag[j][e]); atomic_add_f32(dbeta + ch * 8 + e, ab[j][e]); }
+        for (int e = 0; e < 8; ++e) { red[(wave * 2 + 0) * C + ch * 8 + e] = ag[j][e]; red[(wave * 2 + 1) * C + ch * 8 + e] = ab[j][e]; }
       }
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    const int w = i / C, cc = i - w * C;
+    const float s = red[(0 * 2 + w) * C + cc] + red[(1 * 2 + w) * C + cc] + red[(2 * 2 + w) * C + cc] + red[(3 * 2 + w) * C + cc];
+    atomic_add_f32((w == 0 ? dgamma : dbeta) + cc, s);
   }
 }
 
@@ -551,8 +561,8 @@ extern "C" int osuf_ln_bwd(int dtype, const void* dy, long lddy, const void* x, 
   if (bad_c(C) || M <= 0 || ldx % 8 || lddy % 8 || lddx % 8) return OSUF_EINVAL;
   const int G = pick_group(C / 8);
   long blocks = row_grid(M, G);
-  if (blocks > 1024) blocks = 1024;                   // bounds the dgamma/dbeta atomic traffic
-  DISPATCH_T(dtype, hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3((int)blocks), dim3(256), 0, stream, (const T*)dy, lddy, (const T*)x, ldx,
+  if (blocks > 512) blocks = 512;                     // bounds the dgamma/dbeta atomic traffic (one atomic / channel / block)
+  DISPATCH_T(dtype, hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3((int)blocks), dim3(256), (size_t)8 * C * sizeof(float), stream, (const T*)dy, lddy, (const T*)x, ldx,
                                        (T*)dx, lddx, mr, gamma, dgamma, dbeta, M, C, G));
   return osuf_launch_status();
 }

@@ -41,8 +41,39 @@ def dt_of(t: torch.Tensor) -> int:
     return _DT[t.dtype]
 
 
-def call(name: str, *args) -> None:
+class KernelTimer:
+    """HIP-event timing of selected C-ABI launches on the stream they run on (bench.py's roofline leg)."""
+
+    def __init__(self, names) -> None:
+        self.names = set(names)
+        self.records = {n: [] for n in names}
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for n, recs in self.records.items():
+            if recs:
+                out[n] = dict(launches=len(recs), total_ms=sum(s.elapsed_time(e) for s, e, _ in recs), sizes=[m for _, _, m in recs])
+        return out
+
+
+_TIMER: Optional[KernelTimer] = None
+
+
+def set_kernel_timer(t: Optional[KernelTimer]) -> None:
+    global _TIMER
+    _TIMER = t
+
+
+def call(name: str, *args, meta=None) -> None:
     lib = _lib.load()
+    if _TIMER is not None and name in _TIMER.names:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        _lib.check(getattr(lib, name)(*args), name)
+        e.record()
+        _TIMER.records[name].append((s, e, meta))
+        return
     _lib.check(getattr(lib, name)(*args), name)
 
 
@@ -210,7 +241,7 @@ def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.
     lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     base = qkv.data_ptr()
     call("osuf_mqa_fwd", base, ld, base + 2 * H * D, ld, base + 2 * (H + 1) * D, ld, _p(o), H * D, _DT[out_dtype], _p(lse), B, H, N, D,
-         scale, _stream())
+         scale, _stream(), meta=N)
     return o, lse
 
 
@@ -221,8 +252,11 @@ def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Ten
     dqkv = torch.empty((B, N, W), dtype=torch.float32, device=qkv.device)
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     base, gbase = qkv.data_ptr(), dqkv.data_ptr()
-    call("osuf_mqa_bwd", base, ld, base + 2 * H * D, ld, base + 2 * (H + 1) * D, ld, _p(o), _rows(o)[2], _DT[o.dtype], _p(do), _rows(do)[2],
-         _p(lse), _p(delta), gbase, W, gbase + 4 * H * D, gbase + 4 * (H + 1) * D, W, B, H, N, D, scale, _stream())
+    kp, vp, ldo_ = base + 2 * H * D, base + 2 * (H + 1) * D, _rows(do)[2]
+    call("osuf_attn_delta", _p(do), ldo_, _p(o), _rows(o)[2], _DT[o.dtype], _p(delta), B, H, N, D, _stream())
+    call("osuf_mqa_bwd_dq", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase, W, B, H, N, D, scale, _stream(), meta=N)
+    call("osuf_mqa_bwd_dkv", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase + 4 * H * D, gbase + 4 * (H + 1) * D, W,
+         B, H, N, D, scale, _stream(), meta=N)
     return dqkv
 
 
