@@ -57,15 +57,32 @@ def cpu_baseline(model, length: int, threads: int):
     from oracle import diffusion_oracle as DO
     from oracle import unet_oracle as O
     torch.set_num_threads(threads)
+    print(f"[bench] cpu_baseline: oracle fwd+bwd at B=1, L={length} on {threads} host threads ...", file=sys.stderr, flush=True)
     cfg = O.UNetConfig(dim_h=DIM_H)
     p = {k: v.detach().float().cpu().clone().requires_grad_() for k, v in model.state_dict().items()}
     x, a, c, noise, t = synth_batch(0, "cpu", 1, length)
-    t0 = time.perf_counter()
-    loss = DO.training_loss(p, cfg, x, a, c, noise, t, cond_drop_prob=0.0)
-    loss.backward()
-    dt = time.perf_counter() - t0
+    times = []
+    for it in range(3):                                    # 1 warm-up + 2 timed iterations (bounded: ~10-30 s of CPU work)
+        for v in p.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        loss = DO.training_loss(p, cfg, x, a, c, noise, t, cond_drop_prob=0.0)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+        print(f"[bench] cpu_baseline: iteration {it} fwd+bwd {times[-1]:.1f} s", file=sys.stderr, flush=True)
+    dt = sum(times[1:]) / len(times[1:])
     return dict(value=1.0 / (BATCH * dt), unit="denoise-steps/sec (B=32, linear extrapolation from B=1)", cores=threads, kind="port",
-                sample=f"1 fwd+bwd of the full UNet at B=1, L={length} in {dt:.1f} s (oracle/, fp32 + bf16 SDPA)")
+                sample=f"fwd+bwd of the full UNet at B=1, L={length}: {dt:.2f} s/sample (mean of 2 after 1 warm-up; oracle/, "
+                       f"fp32 + bf16 SDPA as the reference computes on CPU)")
+
+
+def host_threads() -> int:
+    """Threads for the CPU baseline: this process's CPU affinity, capped at the 16-thread share of a 1-GPU box."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
 
 
 def main() -> None:
@@ -101,6 +118,8 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if rank == 0:
+        print(f"[bench] model + data resident; {args.warmup} warmup + {args.steps} timed steps ...", file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         trainer.step(x, a, c, noise, t)
     sync()
@@ -118,6 +137,7 @@ def main() -> None:
         elapsed = tmax.item()
 
     if rank == 0:
+        print(f"[bench] timed region done: {1e3 * elapsed / args.steps:.1f} ms/step", file=sys.stderr, flush=True)
         ms = 1e3 * elapsed / args.steps
         full = (args.batch, args.length, args.dim_h) == (BATCH, LENGTH, DIM_H)
         value = world * args.steps / elapsed * (args.batch / BATCH)
@@ -147,7 +167,7 @@ def main() -> None:
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, args.length, args.cpu_threads or (os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(model, args.length, args.cpu_threads or host_threads())
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
