@@ -10,6 +10,7 @@
 // Global -> registers -> LDS double buffering (one barrier per K-step), XOR-swizzled 16-B chunks so the
 // ds_read_b128 fragment reads are conflict-free; epilogue goes through LDS so HBM stores are full rows.
 #include "common.hpp"
+#include <stdlib.h>
 
 struct RowMap {
   int Lin, Lout, stride, pad, mode;
@@ -56,102 +57,8 @@ static constexpr int kStageBytes = 2 * kTile * 128;   // A tile + B tile, 128 B 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BK = Mma<T>::BK;
-  constexpr int EPC = ElemTraits<T>::kPer16B;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int tiles_n = (g.N + kTile - 1) / kTile;
-  const int m0 = (blockIdx.x / tiles_n) * kTile, n0 = (blockIdx.x % tiles_n) * kTile;
-  const T* A = reinterpret_cast<const T*>(g.A);
-  const T* W = reinterpret_cast<const T*>(g.W);
-
-  // staging assignment: chunk column c (16 B of K), rows r0 + 32*i
-  const int c = tid & 7, r0 = tid >> 3;
-  int a_base[4], a_pos[4];
-  bool b_ok[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int m = m0 + r0 + 32 * i;
-    if (m < g.M) { int b = m / g.rm.Lout; a_base[i] = b * g.rm.Lin; a_pos[i] = m - b * g.rm.Lout; }
-    else { a_base[i] = 0; a_pos[i] = -1; }
-    b_ok[i] = (n0 + r0 + 32 * i) < g.N;
-  }
-  const int ksteps = (g.K + BK - 1) / BK;
-  const int nsteps = g.taps * ksteps;
-
-  u32x4 ra[4], rb[4];
-  auto load_regs = [&](int step) {
-    const int t = step / ksteps, kb = step - t * ksteps;
-    const int k = kb * BK + c * EPC;
-    const bool kok = k < g.K;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      u32x4 z = {0u, 0u, 0u, 0u};
-      ra[i] = z; rb[i] = z;
-      if (kok && a_pos[i] >= 0) {
-        int s = map_row(g.rm, a_pos[i], t);
-        if (s >= 0) ra[i] = *reinterpret_cast<const u32x4*>(A + (long)(a_base[i] + s) * g.lda + k);
-      }
-      if (kok && b_ok[i])
-        rb[i] = *reinterpret_cast<const u32x4*>(W + (long)t * g.tapstride + (long)(n0 + r0 + 32 * i) * g.ldw + k);
-    }
-  };
-  auto store_lds = [&](int buf) {
-    char* sa = smem + buf * kStageBytes;
-    char* sb = sa + kTile * 128;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int off = swz_off(r0 + 32 * i, c);
-      *reinterpret_cast<u32x4*>(sa + off) = ra[i];
-      *reinterpret_cast<u32x4*>(sb + off) = rb[i];
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  load_regs(0);
-  store_lds(0);
-  __syncthreads();
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], char* smem, int m0, int n0, int tid, int lane, int wr, int wc) {
   const int lr = lane & 31, lh = lane >> 5;
-  for (int step = 0; step < nsteps; ++step) {
-    const int buf = step & 1;
-    if (step + 1 < nsteps) load_regs(step + 1);
-    const char* sa = smem + buf * kStageBytes;
-    const char* sb = sa + kTile * 128;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      u32x4 fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = *reinterpret_cast<const u32x4*>(sa + swz_off(wr * 64 + i * 32 + lr, 2 * ks + lh));
-        fb[i] = *reinterpret_cast<const u32x4*>(sb + swz_off(wc * 64 + i * 32 + lr, 2 * ks + lh));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if constexpr (sizeof(T) == 2) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
-                                                                 __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
-          } else {
-            f32x4 va = __builtin_bit_cast(f32x4, fa[i]), vb = __builtin_bit_cast(f32x4, fb[j]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e], vb[e], acc[i][j], 0, 0, 0);
-          }
-        }
-    }
-    if (step + 1 < nsteps) store_lds(buf ^ 1);
-    __syncthreads();
-  }
-
   // ---- epilogue: accumulators -> LDS (fp32 [128][128]) -> coalesced row stores -------------------------
   float* cs = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -244,6 +151,415 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BK = Mma<T>::BK;
+  constexpr int EPC = ElemTraits<T>::kPer16B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_n = (g.N + kTile - 1) / kTile;
+  const int m0 = (blockIdx.x / tiles_n) * kTile, n0 = (blockIdx.x % tiles_n) * kTile;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+
+  // staging assignment: chunk column c (16 B of K), rows r0 + 32*i
+  const int c = tid & 7, r0 = tid >> 3;
+  int a_base[4], a_pos[4];
+  bool b_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + r0 + 32 * i;
+    if (m < g.M) { int b = m / g.rm.Lout; a_base[i] = b * g.rm.Lin; a_pos[i] = m - b * g.rm.Lout; }
+    else { a_base[i] = 0; a_pos[i] = -1; }
+    b_ok[i] = (n0 + r0 + 32 * i) < g.N;
+  }
+  const int ksteps = (g.K + BK - 1) / BK;
+  const int nsteps = g.taps * ksteps;
+
+  // Two statically named register sets: the tile of step s+2 is issued at the top of step s and written to LDS at the
+  // bottom of step s+1, so every global load has ~2 K-steps (>= 1000 MFMA cycles at 2 waves/SIMD) to land.
+  u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+  auto load_regs = [&](int step, u32x4 (&ra)[4], u32x4 (&rb)[4]) {
+    const int t = step / ksteps, kb = step - t * ksteps;
+    const int k = kb * BK + c * EPC;
+    const bool kok = k < g.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 z = {0u, 0u, 0u, 0u};
+      ra[i] = z; rb[i] = z;
+      if (kok && a_pos[i] >= 0) {
+        int s = map_row(g.rm, a_pos[i], t);
+        if (s >= 0) ra[i] = *reinterpret_cast<const u32x4*>(A + (long)(a_base[i] + s) * g.lda + k);
+      }
+      if (kok && b_ok[i])
+        rb[i] = *reinterpret_cast<const u32x4*>(W + (long)t * g.tapstride + (long)(n0 + r0 + 32 * i) * g.ldw + k);
+    }
+  };
+  auto store_lds = [&](int buf, const u32x4 (&ra)[4], const u32x4 (&rb)[4]) {
+    char* sa = smem + buf * kStageBytes;
+    char* sb = sa + kTile * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int off = swz_off(r0 + 32 * i, c);
+      *reinterpret_cast<u32x4*>(sa + off) = ra[i];
+      *reinterpret_cast<u32x4*>(sb + off) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  auto compute = [&](int buf) {
+    const char* sa = smem + buf * kStageBytes;
+    const char* sb = sa + kTile * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *reinterpret_cast<const u32x4*>(sa + swz_off(wr * 64 + i * 32 + lr, 2 * ks + lh));
+        fb[i] = *reinterpret_cast<const u32x4*>(sb + swz_off(wc * 64 + i * 32 + lr, 2 * ks + lh));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (sizeof(T) == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                 __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+          } else {
+            f32x4 va = __builtin_bit_cast(f32x4, fa[i]), vb = __builtin_bit_cast(f32x4, fb[j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e], vb[e], acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+  };
+
+  // prologue: step 0 -> LDS[0]; step 1 in flight in set 1
+  load_regs(0, ra0, rb0);
+  if (nsteps > 1) load_regs(1, ra1, rb1);
+  store_lds(0, ra0, rb0);
+  __syncthreads();
+  for (int step = 0; step < nsteps; step += 2) {
+    // even step: compute LDS[0]; set 1 (step+1) -> LDS[1]; issue step+2 into set 0
+    if (step + 2 < nsteps) load_regs(step + 2, ra0, rb0);
+    compute(0);
+    if (step + 1 < nsteps) store_lds(1, ra1, rb1);
+    __syncthreads();
+    if (step + 1 >= nsteps) break;
+    // odd step: compute LDS[1]; set 0 (step+2) -> LDS[0]; issue step+3 into set 1
+    if (step + 3 < nsteps) load_regs(step + 3, ra1, rb1);
+    compute(1);
+    if (step + 2 < nsteps) store_lds(0, ra0, rb0);
+    __syncthreads();
+  }
+
+  gemm_epilogue<T>(g, acc, smem, m0, n0, tid, lane, wr, wc);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA variant of gemm_nt: tiles go HBM/L2 -> LDS by global_load_lds_dwordx4 (no VGPR staging, no ds_write: the
+// ds_write_b128 path moves only ~79 B/clk/CU and was the bottleneck of the register-staged loop).  One wave-instruction
+// fills 1 KiB = 8 tile rows; the LDS image is lane-linear, so the XOR swizzle is applied to the per-lane SOURCE chunk
+// (cdna_hip_programming.md rule 21) and undone by swz_off() on the read side.  Rows outside the tensor (conv padding,
+// M / N / K tails) read from a 64-byte device zero page.
+// ---------------------------------------------------------------------------------------------------------
+__device__ uint4 g_zero_page[4];
+typedef __attribute__((address_space(1))) const void* gas_ptr;
+typedef __attribute__((address_space(3))) void* las_ptr;
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BK = Mma<T>::BK;
+  constexpr int EPC = ElemTraits<T>::kPer16B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_n = (g.N + kTile - 1) / kTile;
+  const int m0 = (blockIdx.x / tiles_n) * kTile, n0 = (blockIdx.x % tiles_n) * kTile;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  // DMA assignment: instruction i of this wave fills tile rows (wave*4+i)*8 + (lane>>3), LDS chunk position lane&7
+  int a_base[4], a_pos[4], chunk[4];
+  bool b_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    chunk[i] = (lane & 7) ^ ((row >> 1) & 7);            // logical K chunk stored at this lane's LDS position
+    const int m = m0 + row;
+    if (m < g.M) { int b = m / g.rm.Lout; a_base[i] = b * g.rm.Lin; a_pos[i] = m - b * g.rm.Lout; }
+    else { a_base[i] = 0; a_pos[i] = -1; }
+    b_ok[i] = (n0 + row) < g.N;
+  }
+  const int ksteps = (g.K + BK - 1) / BK;
+  const int nsteps = g.taps * ksteps;
+
+  auto issue = [&](int step, int buf) {
+    const int t = step / ksteps, kb = step - t * ksteps;
+    char* sa = smem + buf * kStageBytes + wave * 4096;
+    char* sb = sa + kTile * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = kb * BK + chunk[i] * EPC;
+      const bool kok = k < g.K;
+      const char* pa = zero;
+      const char* pb = zero;
+      if (kok && a_pos[i] >= 0) {
+        int s = map_row(g.rm, a_pos[i], t);
+        if (s >= 0) pa = reinterpret_cast<const char*>(A + (long)(a_base[i] + s) * g.lda + k);
+      }
+      if (kok && b_ok[i]) pb = reinterpret_cast<const char*>(W + (long)t * g.tapstride + (long)(n0 + (wave * 4 + i) * 8 + (lane >> 3)) * g.ldw + k);
+      __builtin_amdgcn_global_load_lds((gas_ptr)pa, (las_ptr)(sa + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gas_ptr)pb, (las_ptr)(sb + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  issue(0, 0);
+  __syncthreads();                                         // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+  for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
+    if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
+    const char* sa = smem + buf * kStageBytes;
+    const char* sb = sa + kTile * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *reinterpret_cast<const u32x4*>(sa + swz_off(wr * 64 + i * 32 + lr, 2 * ks + lh));
+        fb[i] = *reinterpret_cast<const u32x4*>(sb + swz_off(wc * 64 + i * 32 + lr, 2 * ks + lh));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (sizeof(T) == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                 __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+          } else {
+            f32x4 va = __builtin_bit_cast(f32x4, fa[i]), vb = __builtin_bit_cast(f32x4, fb[j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e], vb[e], acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    __syncthreads();
+  }
+  gemm_epilogue<T>(g, acc, smem, m0, n0, tid, lane, wr, wc);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 256x256 block tile, 8 waves (2x4), wave tile 128x64 = 4x2 MFMA tiles, LDS-DMA staging, 2 x 64 KiB ring.
+// Why: at full MFMA rate a 128x128x64 tile needs 64 B/clk/CU of L2->LDS traffic and its 64x64 wave tiles need 256 B/clk of
+// ds_read_b128 -- both AT the CU's limits.  This geometry needs 32 B/clk and 192 B/clk.  One workgroup per CU.
+// Epilogue: each wave transposes its own 64x64 sub-tiles through a private 16 KiB LDS slice (no block barrier).
+// ---------------------------------------------------------------------------------------------------------
+static constexpr int kBig = 256;
+static constexpr int kBigStage = 2 * kBig * 128;        // 64 KiB: A 256 rows + B 256 rows, 128 B of K each
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BK = Mma<T>::BK;
+  constexpr int EPC = ElemTraits<T>::kPer16B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (g.N + kBig - 1) / kBig;
+  const int m0 = (blockIdx.x / tiles_n) * kBig, n0 = (blockIdx.x % tiles_n) * kBig;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  int a_base[4], a_pos[4], chunk[4];
+  bool b_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    chunk[i] = (lane & 7) ^ ((row >> 1) & 7);
+    const int m = m0 + row;
+    if (m < g.M) { int b = m / g.rm.Lout; a_base[i] = b * g.rm.Lin; a_pos[i] = m - b * g.rm.Lout; }
+    else { a_base[i] = 0; a_pos[i] = -1; }
+    b_ok[i] = (n0 + row) < g.N;
+  }
+  const int ksteps = (g.K + BK - 1) / BK;
+  const int nsteps = g.taps * ksteps;
+
+  auto issue = [&](int step, int buf) {
+    const int t = step / ksteps, kb = step - t * ksteps;
+    char* sa = smem + buf * kBigStage + wave * 4096;
+    char* sb = sa + kBig * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = kb * BK + chunk[i] * EPC;
+      const bool kok = k < g.K;
+      const char* pa = zero;
+      const char* pb = zero;
+      if (kok && a_pos[i] >= 0) {
+        int s = map_row(g.rm, a_pos[i], t);
+        if (s >= 0) pa = reinterpret_cast<const char*>(A + (long)(a_base[i] + s) * g.lda + k);
+      }
+      if (kok && b_ok[i]) pb = reinterpret_cast<const char*>(W + (long)t * g.tapstride + (long)(n0 + (wave * 4 + i) * 8 + (lane >> 3)) * g.ldw + k);
+      __builtin_amdgcn_global_load_lds((gas_ptr)pa, (las_ptr)(sa + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gas_ptr)pb, (las_ptr)(sb + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  issue(0, 0);
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
+    if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
+    const char* sa = smem + buf * kBigStage;
+    const char* sb = sa + kBig * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 fa[4], fb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(sa + swz_off(wr * 128 + i * 32 + lr, 2 * ks + lh));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const u32x4*>(sb + swz_off(wc * 64 + j * 32 + lr, 2 * ks + lh));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (sizeof(T) == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                 __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+          } else {
+            f32x4 va = __builtin_bit_cast(f32x4, fa[i]), vb = __builtin_bit_cast(f32x4, fb[j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e], vb[e], acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: per wave, two passes of a 64x64 fp32 sub-tile through its private 16 KiB LDS slice --------
+  float* cs = reinterpret_cast<float*>(smem + wave * 16384);
+  float* sstat = reinterpret_cast<float*>(smem + 2 * kBigStage);
+  int sb0 = 0;
+  if (g.stats) {
+    sb0 = m0 / g.rm.Lout;
+    if (tid < 2 * 66) sstat[tid] = 0.f;
+    __syncthreads();
+  }
+  T* C = reinterpret_cast<T*>(g.C);
+  T* C2 = reinterpret_cast<T*>(g.C2);
+  const T* R = reinterpret_cast<const T*>(g.R);
+  const T* U = reinterpret_cast<const T*>(g.U);
+  const int col4 = (lane & 15) * 4;                       // 16 lanes per 64-column row, 4 rows per pass
+  const int n = n0 + wc * 64 + col4;
+  const bool nok = n < g.N;
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias && nok) { f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n); bias4[0] = b[0]; bias4[1] = b[1]; bias4[2] = b[2]; bias4[3] = b[3]; }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          cs[row * 64 + j * 32 + lr] = acc[half * 2 + i][j][r];
+        }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): this wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + (lane >> 4);
+      const int m = m0 + wr * 128 + half * 64 + row;
+      float s1 = 0.f, s2 = 0.f;
+      int bidx = 0;
+      if (m < g.M && nok) {
+        f32x4 a4 = *reinterpret_cast<const f32x4*>(cs + row * 64 + col4);
+        float v[4] = {a4[0] + bias4[0], a4[1] + bias4[1], a4[2] + bias4[2], a4[3] + bias4[3]};
+        if (C2) store4(C2 + (long)m * g.ldc2 + n, v);
+        if (g.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+        } else if (g.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = sigmoid_f(v[e]);
+        }
+        if (U) {
+          float u[4];
+          load4(U + (long)m * g.ldu + n, u);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= silu_grad_f(u[e]);
+        }
+        bidx = m / g.rm.Lout;
+        if (R) {
+          float rr[4];
+          load4(R + (long)m * g.ldr + n, rr);
+          if (g.rscale) {
+            f32x4 sc = *reinterpret_cast<const f32x4*>(g.rscale + (long)bidx * g.N + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += rr[e] * sc[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += rr[e];
+          }
+        }
+        store4(C + (long)m * g.ldc + n, v);
+        if (g.stats) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { float q = ElemTraits<T>::rnd(v[e]); s1 += q; s2 += q * q; }
+        }
+      }
+      if (g.stats) {
+        s1 = group_sum<16>(s1);
+        s2 = group_sum<16>(s2);
+        if ((lane & 15) == 0 && m < g.M) {
+          int slot = bidx - sb0;
+          if (slot < 66) { atomicAdd(&sstat[2 * slot], s1); atomicAdd(&sstat[2 * slot + 1], s2); }
+          else { atomic_add_f64(g.stats + 2 * (long)bidx, (double)s1); atomic_add_f64(g.stats + 2 * (long)bidx + 1, (double)s2); }
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (g.stats) {
+    __syncthreads();
+    if (tid < 2 * 66) {
+      int slot = tid >> 1;
+      long b = sb0 + slot;
+      float v = sstat[tid];
+      if (v != 0.f && b * g.rm.Lout < g.M) atomic_add_f64(g.stats + 2 * b + (tid & 1), (double)v);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // wgrad: dW[t][n1][n2] += sum_m dY[m][n1] * X[rowmap(m,t)][n2]
 // ---------------------------------------------------------------------------------------------------------
@@ -258,7 +574,7 @@ struct WgradArgs {
 // bf16 tile: [64 rows][128 cols] (256 B/row), byte-in-row ^= (row&3)<<6 -> ds_read_b64_tr_b16 conflict-free
 // f32  tile: [32 rows][128 cols] (512 B/row), plain ds_read_b32 (lanes = consecutive columns)
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool kBF = sizeof(T) == 2;
   constexpr int BKM = kBF ? 64 : 32;                // rows of m per step
@@ -281,8 +597,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs g) {
   constexpr int RSTEP = 256 / CPR;                  // 16 (bf16) / 8 (f32)
   const bool y_ok = (n1_0 + c * EPC) < g.N1, x_ok = (n2_0 + c * EPC) < g.N2;
 
-  u32x4 ry[4], rx[4];
-  auto load_regs = [&](int mb) {
+  u32x4 ry0[4], rx0[4], ry1[4], rx1[4];
+  auto load_regs = [&](int mb, u32x4 (&ry)[4], u32x4 (&rx)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       u32x4 z = {0u, 0u, 0u, 0u};
@@ -298,7 +614,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs g) {
       }
     }
   };
-  auto store_lds = [&](int buf) {
+  auto store_lds = [&](int buf, const u32x4 (&ry)[4], const u32x4 (&rx)[4]) {
     char* sy = smem + buf * 2 * TILEB;
     char* sx = sy + TILEB;
 #pragma unroll
@@ -322,13 +638,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs g) {
   // transposed-read lane roles (ds_read_b64_tr_b16 works per 16-lane group; see cdna_hip_programming.md T10)
   const int ip = lane & 15, cb = ((lane >> 4) & 1) * 16, tq = ip >> 2, tp = ip & 3;
 
-  load_regs(m_begin);
-  store_lds(0);
-  __syncthreads();
-  int buf = 0;
-  for (int mb = m_begin; mb < m_end; mb += BKM, buf ^= 1) {
-    const bool more = mb + BKM < m_end;
-    if (more) load_regs(mb + BKM);
+  auto compute = [&](int buf) {
     const char* sy = smem + buf * 2 * TILEB;
     const char* sx = sy + TILEB;
     if constexpr (kBF) {
@@ -375,7 +685,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(WgradArgs g) {
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (more) store_lds(buf ^ 1);
+  };
+
+  load_regs(m_begin, ry0, rx0);
+  if (m_begin + BKM < m_end) load_regs(m_begin + BKM, ry1, rx1);
+  store_lds(0, ry0, rx0);
+  __syncthreads();
+  for (int mb = m_begin; mb < m_end; mb += 2 * BKM) {
+    if (mb + 2 * BKM < m_end) load_regs(mb + 2 * BKM, ry0, rx0);
+    compute(0);
+    if (mb + BKM < m_end) store_lds(1, ry1, rx1);
+    __syncthreads();
+    if (mb + BKM >= m_end) break;
+    if (mb + 3 * BKM < m_end) load_regs(mb + 3 * BKM, ry1, rx1);
+    compute(1);
+    if (mb + 2 * BKM < m_end) store_lds(0, ry0, rx0);
     __syncthreads();
   }
 
@@ -455,12 +779,27 @@ extern "C" int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, l
   if (!attr_done) {
     hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute((const void*)gemm_nt_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  if (dtype == OSUF_DT_BF16) {
-    hipLaunchKernelGGL(gemm_nt_kernel<bf16_t>, dim3(grid), dim3(256), lds, stream, g);
+  static const bool regstage = getenv("OSUF_GEMM_REGSTAGE") != nullptr;      // A/B switches for profiling only
+  // 256^2 tiles once they fill most of the 256 CUs; OSUF_GEMM_BIG_MIN_TILES overrides the threshold (tests force 1, "off" = never)
+  const char* bigenv = getenv("OSUF_GEMM_BIG_MIN_TILES");
+  const long min_tiles = bigenv ? atol(bigenv) : 192;
+  const long big_tiles = (long)((M + kBig - 1) / kBig) * ((N + kBig - 1) / kBig);
+  const bool use_big = !regstage && dtype == OSUF_DT_BF16 && min_tiles > 0 && big_tiles >= min_tiles && (N >= 192 || bigenv);
+  if (use_big) {
+    const int lds_big = 2 * kBigStage + 1024;
+    static bool big_attr = false;
+    if (!big_attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big); big_attr = true; }
+    hipLaunchKernelGGL(gemm_nt_big_kernel<bf16_t>, dim3((int)big_tiles), dim3(512), lds_big, stream, g);
+  } else if (regstage) {
+    if (dtype == OSUF_DT_BF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16_t>, dim3(grid), dim3(256), lds, stream, g);
+    else hipLaunchKernelGGL(gemm_nt_kernel<float>, dim3(grid), dim3(256), lds, stream, g);
   } else {
-    hipLaunchKernelGGL(gemm_nt_kernel<float>, dim3(grid), dim3(256), lds, stream, g);
+    if (dtype == OSUF_DT_BF16) hipLaunchKernelGGL(gemm_nt_glds_kernel<bf16_t>, dim3(grid), dim3(256), lds, stream, g);
+    else hipLaunchKernelGGL(gemm_nt_glds_kernel<float>, dim3(grid), dim3(256), lds, stream, g);
   }
   return osuf_launch_status();
 }

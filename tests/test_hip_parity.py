@@ -111,6 +111,38 @@ def test_conv_fn_forward_backward(dtype, tol, kind, k, L):
     assert relmax(b.grad, gq.sum((0, 2))) < tol
 
 
+@pytest.mark.parametrize("kind,k,L", [("same", 3, 200), ("same", 1, 520), ("down", 3, 96), ("up", 3, 56), ("same", 15, 64)])
+def test_big_tile_gemm_kernel(monkeypatch, kind, k, L):
+    """The 256x256 8-wave LDS-DMA kernel is normally selected only for chip-filling shapes; force it on small ragged ones
+    (M, N, K tails, every row-map mode, every epilogue option) and compare with the 128x128 kernel bit for bit."""
+    Cin, Cout = 72, 328
+    x = torch.randn(B, L, Cin, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin, k, device=DEV) / (Cin * k) ** 0.5)
+    bias = torch.randn(Cout, device=DEV)
+    Lout = {"same": L, "down": L // 2, "up": 2 * L}[kind]
+    res = torch.randn(B, Lout, Cout, device=DEV).to(torch.bfloat16)
+    rscale = torch.rand(B, Cout, device=DEV)
+    outs = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("OSUF_GEMM_BIG_MIN_TILES", force)
+        stats = torch.zeros(B, 2, dtype=torch.float64, device=DEV)
+        y, pre = Fn.conv_forward(x, w, bias, Fn.PackCache(), kind, None, act=1, residual=res, rscale=rscale, stats=stats, want_pre=True)
+        dx = Fn.conv_dgrad(y, w, Fn.PackCache(), kind, L, residual=x)
+        outs.append((y.float(), pre.float(), stats.clone(), dx.float()))
+    monkeypatch.delenv("OSUF_GEMM_BIG_MIN_TILES")
+    (y0, p0, s0, d0), (y1, p1, s1, d1) = outs
+    assert torch.equal(y0, y1) and torch.equal(p0, p1) and torch.equal(d0, d1)
+    assert torch.allclose(s0, s1, rtol=1e-6)
+    xq, wq = x.float(), w.to(torch.bfloat16).float()
+    if kind == "same":
+        ref = F.conv1d(xq.permute(0, 2, 1), wq, bias, padding=k // 2)
+    elif kind == "down":
+        ref = F.conv1d(F.pad(xq.permute(0, 2, 1), (0, 1), mode="reflect"), wq, bias, stride=2)
+    else:
+        ref = F.conv1d(F.interpolate(xq.permute(0, 2, 1), scale_factor=2.0, mode="nearest"), wq, bias, padding=1)
+    assert relmax(p1.permute(0, 2, 1), ref) < 1e-2
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("film", [False, True])
 def test_block_fn(dtype, tol, film):
