@@ -10,6 +10,7 @@
 // Backward = two kernels without atomics: dQ (query-stationary, same loop as forward) and dK/dV
 // (key-stationary: a wave owns 32 keys, dK^T/dV^T stay in registers while it sweeps heads x query blocks).
 #include "common.hpp"
+#include <type_traits>
 
 static constexpr int D = 64;                      // head dim (bytes per tile row = 128)
 static constexpr float kLog2e = 1.4426950408889634f;
@@ -22,28 +23,47 @@ __device__ __forceinline__ int tile_off(int row, int colbyte) {
   return row * 128 + ((((colbyte >> 4) ^ f) << 4) | (colbyte & 15));
 }
 
-__device__ __forceinline__ bf16x8 lds_row_frag(const char* tile, int row, int chunk) {
-  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tile + tile_off(row, chunk * 16)));
+// Loop-invariant per-lane LDS byte offsets (the XOR swizzle makes them non-affine in the k-step, so they are precomputed
+// once; everything that varies inside the tile loop is a compile-time row base folded into the ds instruction's offset).
+struct LaneOffs {
+  int row[4];      // row read of tile row (lane&31) (+32*n rows = +4096*n B), K chunk 2*ks + (lane>>5)
+  int tr[2][2];    // transposed read, [dt][variant]: variant = bit 3 of the row base (it flips one swizzle bit)
+  __device__ __forceinline__ explicit LaneOffs(int lane) {
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) row[ks] = tile_off(lr, (2 * ks + lh) * 16);
+    const int cb = ((lane >> 4) & 1) * 16, ip = lane & 15, tq = ip >> 2, tp = ip & 3;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int var = 0; var < 2; ++var) tr[dt][var] = tile_off(8 * var + 4 * lh + tq, (dt * 32 + cb + 4 * tp) * 2) - 8 * var * 128;
+  }
+};
+
+__device__ __forceinline__ bf16x8 lds_row_frag(const char* tile, const LaneOffs& lo, int ks, int rowblock32) {
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tile + lo.row[ks] + rowblock32 * 4096));
 }
 
 // A-operand fragment of a TRANSPOSED tile read: element e of lane (r = lane&31, h = lane>>5) =
-//   tile[rowbase + 8*(e>>2) + 4*h + (e&3)][colbase + r]      (the k order of an accumulator used as B operand)
-__device__ __forceinline__ bf16x8 lds_tr_frag(const char* tile, int rowbase, int colbase, int lane) {
-  const int lh = lane >> 5, cb = ((lane >> 4) & 1) * 16, ip = lane & 15, tq = ip >> 2, tp = ip & 3;
-  const int colbyte = (colbase + cb + 4 * tp) * 2;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + tile_off(rowbase + 4 * lh + tq, colbyte)));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + tile_off(rowbase + 8 + 4 * lh + tq, colbyte)));
+//   tile[rowbase + 8*(e>>2) + 4*h + (e&3)][dt*32 + r]      (the k order of an accumulator used as B operand)
+// rowbase must be a multiple of 8 (compile-time in the unrolled loops).
+__device__ __forceinline__ bf16x8 lds_tr_frag(const char* tile, const LaneOffs& lo, int rowbase, int dt) {
+  const int v0 = (rowbase >> 3) & 1;
+  s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + lo.tr[dt][v0] + rowbase * 128));
+  s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + lo.tr[dt][v0 ^ 1] + (rowbase + 8) * 128));
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// registers 8*sub .. 8*sub+7 of a 32x32 accumulator -> bf16x8 B-operand fragment (k order permuted, see above)
+// registers 8*sub .. 8*sub+7 of a 32x32 accumulator -> bf16x8 B-operand fragment (k order permuted, see above);
+// __builtin_convertvector lowers to four two-operand v_cvt_pk_bf16_f32
 __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int sub) {
-  u32x4 r;
+  typedef __attribute__((ext_vector_type(8))) float f32x8;
+  f32x8 v;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = pack_bf16x2(a[8 * sub + 2 * i], a[8 * sub + 2 * i + 1]);
-  return __builtin_bit_cast(bf16x8, r);
+  for (int i = 0; i < 8; ++i) v[i] = a[8 * sub + i];
+  return __builtin_convertvector(v, bf16x8);
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -84,6 +104,8 @@ struct KVStage {
 
 // ------------------------------------------------------------------------------------------------------
 // forward
+// (A two-wave-group variant skewed by half a tile with LDS-DMA staging was measured at 590-605 TFLOP/s against 803 for
+//  this single-phase loop -- two barriers per tile and the serial MFMA -> max -> exp chain cost more than the overlap won.)
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void mqa_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][K 8K | V 8K]
@@ -115,12 +137,15 @@ __global__ __launch_bounds__(512) void mqa_fwd_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
+  const LaneOffs lo(lane);
   const int ntiles = (a.N + 63) >> 6;
   KVStage st;
   st.load(a, b, 0, tid);
   st.store(smem, smem + 8192, tid);
   __syncthreads();
-  for (int j = 0; j < ntiles; ++j) {
+  // one 64-key tile; MASK only for a ragged last tile (a branch-free mask on every tile costs 64 VALU ops per tile)
+  auto tile = [&](int j, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
     const char* ks_ = smem + (j & 1) * 16384;
     const char* vs_ = ks_ + 8192;
     if (j + 1 < ntiles) st.load(a, b, (j + 1) * 64, tid);
@@ -132,9 +157,9 @@ __global__ __launch_bounds__(512) void mqa_fwd_kernel(AttnArgs a) {
       for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(ks_, kt * 32 + lr, 2 * ks + lh), qf[ks], s[kt], 0, 0, 0);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(ks_, lo, ks, kt), qf[ks], s[kt], 0, 0, 0);
     }
-    if ((j + 1) * 64 > a.N) {                      // ragged last tile: mask keys >= N
+    if constexpr (MASK) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -148,35 +173,45 @@ __global__ __launch_bounds__(512) void mqa_fwd_kernel(AttnArgs a) {
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * c);
-    const float alpha = fast_exp2(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
+    // lazy rescale: keep the running max while no row's max grew by more than 2^6 (P <= 64: bf16 rounding is scale-free);
+    // the branch is wave-uniform
+    if (__any(mx > m_run + 6.0f)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = fast_exp2(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    }
+    float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float p = fast_exp2(s[kt][r] * c - m_new);
-        s[kt][r] = p;
-        psum += p;
+      for (int r = 0; r < 16; r += 2) {
+        float p0 = fast_exp2(fmaf(s[kt][r], c, -m_run));
+        float p1 = fast_exp2(fmaf(s[kt][r + 1], c, -m_run));
+        s[kt][r] = p0; s[kt][r + 1] = p1;
+        ps0 += p0; ps1 += p1;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    l_run += ps0 + ps1;
     // O^T += V^T P^T
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       const bf16x8 pf = acc_to_frag(s[s4 >> 1], s4 & 1);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(vs_, (s4 >> 1) * 32 + (s4 & 1) * 16, dt * 32, lane), pf, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(vs_, lo, (s4 >> 1) * 32 + (s4 & 1) * 16, dt), pf, o[dt], 0, 0, 0);
     }
     if (j + 1 < ntiles) st.store(smem + ((j + 1) & 1) * 16384, smem + ((j + 1) & 1) * 16384 + 8192, tid);
     __syncthreads();
-  }
+  };
+  const bool ragged = (a.N & 63) != 0;
+  for (int j = 0; j < ntiles - 1; ++j) tile(j, std::false_type{});
+  if (ragged) tile(ntiles - 1, std::true_type{});
+  else tile(ntiles - 1, std::false_type{});
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (qok) {
     const float inv = 1.f / l_tot;
@@ -233,6 +268,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+  const LaneOffs lo(lane);
   const int ntiles = (a.N + 63) >> 6;
   KVStage st;
   st.load(a, b, 0, tid);
@@ -249,8 +285,8 @@ __global__ __launch_bounds__(512) void mqa_bwd_dq_kernel(AttnArgs a) {
       for (int r = 0; r < 16; ++r) { s[kt][r] = 0.f; dp[kt][r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(ks_, kt * 32 + lr, 2 * ks + lh), qf[ks], s[kt], 0, 0, 0);
-        dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(vs_, kt * 32 + lr, 2 * ks + lh), dof[ks], dp[kt], 0, 0, 0);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(ks_, lo, ks, kt), qf[ks], s[kt], 0, 0, 0);
+        dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(vs_, lo, ks, kt), dof[ks], dp[kt], 0, 0, 0);
       }
     }
     // dS^T = P^T * (dP^T - delta) * scale   (zero K rows make masked keys contribute nothing)
@@ -258,7 +294,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_dq_kernel(AttnArgs a) {
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = fast_exp2(s[kt][r] * c - L2);
+        float p = fast_exp2(fmaf(s[kt][r], c, -L2));
         s[kt][r] = p * (dp[kt][r] - dl) * a.scale;
       }
 #pragma unroll
@@ -266,7 +302,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_dq_kernel(AttnArgs a) {
       const bf16x8 df = acc_to_frag(s[s4 >> 1], s4 & 1);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
-        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(ks_, (s4 >> 1) * 32 + (s4 & 1) * 16, dt * 32, lane), df, acc[dt], 0, 0, 0);
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(ks_, lo, (s4 >> 1) * 32 + (s4 & 1) * 16, dt), df, acc[dt], 0, 0, 0);
     }
     if (j + 1 < ntiles) st.store(smem + ((j + 1) & 1) * 16384, smem + ((j + 1) & 1) * 16384 + 8192, tid);
     __syncthreads();
@@ -343,6 +379,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_kernel(AttnArgs a) {
     if (tid < 64) reinterpret_cast<float*>(base + 8192)[tid] = rs;
   };
 
+  const LaneOffs lo(lane);
   load_stage(0);
   store_stage(0);
   __syncthreads();
@@ -357,8 +394,8 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(qs, lr, 2 * ks + lh), kf[ks], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(dos, lr, 2 * ks + lh), vf[ks], dp, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(qs, lo, ks, 0), kf[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(dos, lo, ks, 0), vf[ks], dp, 0, 0, 0);
     }
     f32x16 ds;
 #pragma unroll
@@ -368,7 +405,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
-        float p = fast_exp2(s[r] * c - l4[e]);
+        float p = fast_exp2(fmaf(s[r], c, -l4[e]));
         s[r] = p;
         ds[r] = p * (dp[r] - d4[e]) * a.scale;
       }
@@ -380,8 +417,8 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_kernel(AttnArgs a) {
       const bf16x8 df = acc_to_frag(ds, s2);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(dos, s2 * 16, dt * 32, lane), pf, dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(qs, s2 * 16, dt * 32, lane), df, dk[dt], 0, 0, 0);
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(dos, lo, s2 * 16, dt), pf, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(qs, lo, s2 * 16, dt), df, dk[dt], 0, 0, 0);
       }
     }
     if (it + 1 < niter) store_stage((it + 1) & 1);
