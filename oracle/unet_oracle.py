@@ -180,6 +180,16 @@ class Numerics:
         """An activation tensor written to HBM by the HIP path."""
         return _RoundBF16.apply(x) if self.mode == "bf16" else x
 
+    def lin(self, x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+        """An embedding-sized Linear / 1x1 conv on (B, K): fp32 in the fp32 run; bf16 operands, fp32 accumulate and a
+        bf16-stored result in bf16 mode (what torch autocast does to nn.Linear, and what the HIP path does)."""
+        w2 = w.reshape(w.shape[0], -1)
+        if self.mode == "bf16":
+            return self.act(F.linear(self.act(x), self.w(w2), b))
+        if w.dim() == 3:                                   # fp32 run: the reference's own op (1x1 Conv1d on (B, C, 1))
+            return F.conv1d(x[..., None], w, b)[..., 0]
+        return F.linear(x, w2, b)
+
     def w(self, w: Tensor) -> Tensor:
         """A GEMM/conv weight operand (bf16 pack of the fp32 master in bf16 mode)."""
         if self.mode == "bf16":
@@ -210,11 +220,10 @@ def global_context(p: Dict[str, Tensor], pre: str, h: Tensor, nm: Numerics) -> T
     """residual.py:29-32.  h: (B,C,N) -> gate (B,C,1).  Pooling in fp32 in both modes."""
     logits = F.conv1d(h, p[f"{pre}.to_k.weight"], p[f"{pre}.to_k.bias"])         # (B,1,N)
     w = logits.softmax(dim=-1)
-    pooled = torch.einsum("bcn,bjn->bcj", h, w)                                   # (B,C,1)
-    g = F.conv1d(pooled, p[f"{pre}.layers.0.weight"], p[f"{pre}.layers.0.bias"])
-    g = F.silu(g)
-    g = F.conv1d(g, p[f"{pre}.layers.2.weight"], p[f"{pre}.layers.2.bias"])
-    return torch.sigmoid(g)
+    pooled = torch.einsum("bcn,bjn->bcj", h, w)[..., 0]                           # (B,C)
+    g = nm.lin(pooled, p[f"{pre}.layers.0.weight"], p[f"{pre}.layers.0.bias"])
+    g = nm.lin(F.silu(g), p[f"{pre}.layers.2.weight"], p[f"{pre}.layers.2.bias"])
+    return torch.sigmoid(g)[..., None]
 
 
 def block(p, pre, x, scale_shift, nm: Numerics) -> Tensor:
@@ -233,7 +242,7 @@ def residual_block(p, pre, x, t, c, nm: Numerics) -> Tensor:
     scale_shift = None
     if f"{pre}.mlp.1.weight" in p:
         emb = torch.cat([e for e in (t, c) if e is not None], dim=-1)
-        emb = F.linear(F.silu(emb), p[f"{pre}.mlp.1.weight"], p[f"{pre}.mlp.1.bias"])   # SiLU first (residual.py:106)
+        emb = nm.lin(F.silu(emb), p[f"{pre}.mlp.1.weight"], p[f"{pre}.mlp.1.bias"])     # SiLU first (residual.py:106)
         emb = emb[:, :, None]
         scale_shift = emb.chunk(2, dim=1)
     h = block(p, f"{pre}.block1", x, scale_shift, nm)
@@ -350,8 +359,8 @@ def unet_forward(p: Dict[str, Tensor], cfg: UNetConfig, x: Tensor, a: Tensor, t:
     a = audio_encoder(p, f"{P}audio_encoder", a, cfg, nm)
     E = cfg.dim_emb
     te = sinusoidal_embedding(t, E)
-    te = F.linear(te, p[f"{P}time_mlp.1.weight"], p[f"{P}time_mlp.1.bias"])
-    te = F.linear(F.silu(te), p[f"{P}time_mlp.3.weight"], p[f"{P}time_mlp.3.bias"])
+    te = nm.lin(te, p[f"{P}time_mlp.1.weight"], p[f"{P}time_mlp.1.bias"])
+    te = nm.lin(F.silu(te), p[f"{P}time_mlp.3.weight"], p[f"{P}time_mlp.3.bias"])
     r = x
 
     B = x.shape[0]
@@ -363,8 +372,8 @@ def unet_forward(p: Dict[str, Tensor], cfg: UNetConfig, x: Tensor, a: Tensor, t:
             cond_mask = torch.ones(B, dtype=torch.bool)
         else:
             cond_mask = torch.zeros(B).uniform_(0.0, 1.0) < keep
-    ce = F.linear(c, p[f"{P}cond_mlp.0.weight"], p[f"{P}cond_mlp.0.bias"])
-    ce = F.linear(F.silu(ce), p[f"{P}cond_mlp.2.weight"], p[f"{P}cond_mlp.2.bias"])
+    ce = nm.lin(c, p[f"{P}cond_mlp.0.weight"], p[f"{P}cond_mlp.0.bias"])
+    ce = nm.lin(F.silu(ce), p[f"{P}cond_mlp.2.weight"], p[f"{P}cond_mlp.2.bias"])
     ce = torch.where(cond_mask[:, None], ce, p[f"{P}null_cond"][None, :].expand(B, E))
 
     L = len(cfg.dim_h_mult)

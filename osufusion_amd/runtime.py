@@ -93,8 +93,13 @@ def cast_rows(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 
 def small_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], cache: Fn.PackCache, tag: str) -> torch.Tensor:
-    """fp32 (B, K) @ w(N, K)^T + b through the f32-MFMA GEMM (embedding-sized MLPs stay fp32 in every mode)."""
+    """(B, K) @ w(N, K)^T + b for the embedding-sized MLPs (time / cond / FiLM / GlobalContext), fp32 in, fp32 out.
+
+    The GEMM runs in the compute dtype, as the reference does: fp32 run -> exact-f32 MFMA; bf16 autocast -> bf16 operands with
+    fp32 accumulation (torch autocast casts nn.Linear / 1x1 Conv1d to bf16 too).  The f32 MFMA runs at 1/16 of the bf16 rate,
+    which made these 280 M=32 GEMMs cost 18 ms of a 340 ms bf16 step when they were pinned to fp32."""
     require_gpu(x)
+    dt = compute_dtype(w.dtype)
     K = x.shape[-1]
     x = x.float()
     w2 = w.reshape(w.shape[0], -1).float()
@@ -107,6 +112,7 @@ def small_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], ca
     if padn:
         w2 = torch.nn.functional.pad(w2, (0, 0, 0, padn))
         b = torch.nn.functional.pad(b, (0, padn)) if b is not None else None
-    y = Fn.ConvFn.apply(x.contiguous().unsqueeze(0), w2, b.float() if b is not None else None, cache, "same", (tag, w))
-    y = y.squeeze(0)
+    xr = cast_rows(x.contiguous().unsqueeze(0), dt)
+    y = Fn.ConvFn.apply(xr, w2, b.float() if b is not None else None, cache, "same", (tag, w))
+    y = cast_rows(y, torch.float32).squeeze(0)
     return y[:, :N] if padn else y

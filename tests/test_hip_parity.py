@@ -177,7 +177,7 @@ def test_global_context_and_gate(dtype, tol):
     gc = load_pattern(R.GlobalContext(C, C).to(DEV))
     p = {"m." + k: v.detach().cpu().clone().requires_grad_() for k, v in gc.state_dict().items()}
     hr = h.cpu().clone().requires_grad_()
-    ref_gate = O.global_context(p, "m", hr, O.Numerics("fp32"))
+    ref_gate = O.global_context(p, "m", hr, O.Numerics("bf16" if dtype == torch.bfloat16 else "fp32"))
     res = torch.randn(B, C, L).to(dtype).float()
     ref = hr * ref_gate + res
     rows = h.detach().permute(0, 2, 1).contiguous().to(dtype).clone().requires_grad_()
