@@ -19,7 +19,8 @@ P, L, I, F = c_void_p, c_long, c_int, c_float
 SIGNATURES = {
     "osuf_version": [],
     "osuf_gemm_nt": [I, P, L, P, L, L, P, L, P, L, P, L, P, L, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
-    "osuf_gemm_tn": [I, P, L, P, L, P, L, L, I, I, I, I, I, I, I, I, I, I, P],
+    "osuf_gemm_tn": [I, P, L, P, L, P, L, L, I, I, I, I, I, I, I, I, I, I, P, L, P],
+    "osuf_gemm_tn_workspace_bytes": [I, I, I, I, I],
     "osuf_colsum": [I, P, L, I, I, P, P],
     "osuf_gn_finalize": [P, P, I, L, P],
     "osuf_gn_apply_fwd": [I, P, L, P, L, P, P, P, P, I, I, I, P],
@@ -77,7 +78,7 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_long if name.endswith("_bytes") else c_int
     _lib = lib
     return lib
 

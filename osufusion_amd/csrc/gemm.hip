@@ -384,7 +384,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int tiles_n = (g.N + kBig - 1) / kBig;
-  const int m0 = (blockIdx.x / tiles_n) * kBig, n0 = (blockIdx.x % tiles_n) * kBig;
+  // XCD-aware tile order (speed only): block ids are dealt round-robin to the 8 XCDs, so the N-tiles that share one
+  // M-tile's A rows get ids 8 apart -> same XCD (same L2), dispatched back to back.
+  const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;
+  const int mt = (qid / tiles_n) * 8 + xcd;
+  const int m0 = mt * kBig, n0 = (qid % tiles_n) * kBig;
+  if (m0 >= g.M) return;
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* W = reinterpret_cast<const T*>(g.W);
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
@@ -565,6 +570,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(GemmArgs g) {
 // ---------------------------------------------------------------------------------------------------------
 struct WgradArgs {
   const void* dY; const void* X; float* dW;
+  float* ws;                       // optional [splits][taps][N1][N2] partial tiles (plain stores) instead of atomics
   long ldy, ldx, ldw, tapstride;
   int M, N1, N2, taps;
   RowMap rm;
@@ -719,6 +725,181 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 256x256 output tile wgrad (bf16): 8 waves (2x4), wave tile 128 (n1) x 64 (n2), 64 rows of m per step, LDS-DMA staging into a
+// 2 x 64 KiB ring.  Tiles are row-major as stored ([64 rows][256 cols] = 512 B per row); chunk ^= (row&3)<<2 keeps the
+// ds_read_b64_tr_b16 fragment reads conflict-free.  The transposed reads are issued through inline asm (hipcc guards the
+// ds_read_tr16 intrinsic with vmcnt(0) while an LDS-DMA is in flight) and software-pipelined one k-step ahead of the MFMAs.
+// ---------------------------------------------------------------------------------------------------------
+#define OSUF_TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(WgradArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKM = 64, ROWB = 512, TILEB = BKM * ROWB;      // 32 KiB per operand tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n2 = (g.N2 + kBig - 1) / kBig;
+  const int tiles_n1 = (g.N1 + kBig - 1) / kBig;
+  // XCD-aware order (speed only): the taps of one (split, tile) unit re-read identical dY / X bytes; give them ids 8 apart
+  // so they share one XCD's L2 and run back to back, and deal the units themselves round-robin over the 8 XCDs.
+  const int ntile = tiles_n1 * tiles_n2;
+  const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;
+  const int unit = (qid / g.taps) * 8 + xcd;
+  const int t = qid % g.taps;
+  const int split = unit / ntile, tile = unit % ntile;
+  const int n1_0 = (tile / tiles_n2) * kBig, n2_0 = (tile % tiles_n2) * kBig;
+  const int m_begin = split * g.rows_per_split;
+  const int m_end = min(g.M, m_begin + g.rows_per_split);
+  if (m_begin >= m_end) return;
+  const bf16_t* dY = reinterpret_cast<const bf16_t*>(g.dY);
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(g.X);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  // DMA role: instruction i of this wave fills tile rows (wave*4+i)*2 + (lane>>5), LDS chunk position lane&31
+  int srow[4], scol[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    srow[i] = (wave * 4 + i) * 2 + (lane >> 5);
+    scol[i] = ((lane & 31) ^ ((srow[i] & 3) << 2)) * 8;        // logical column (elements) stored at this LDS position
+  }
+  auto issue = [&](int mb, int buf) {
+    char* sy = smem + buf * 2 * TILEB + wave * 4096;
+    char* sx = sy + TILEB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mb + srow[i];
+      const char* py = zero;
+      const char* px = zero;
+      if (m < m_end) {
+        if (n1_0 + scol[i] < g.N1) py = reinterpret_cast<const char*>(dY + (long)m * g.ldy + n1_0 + scol[i]);
+        if (n2_0 + scol[i] < g.N2) {
+          const int b = m / g.rm.Lout;
+          const int s2 = map_row(g.rm, m - b * g.rm.Lout, t);
+          if (s2 >= 0) px = reinterpret_cast<const char*>(X + (long)(b * g.rm.Lin + s2) * g.ldx + n2_0 + scol[i]);
+        }
+      }
+      __builtin_amdgcn_global_load_lds((gas_ptr)py, (las_ptr)(sy + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gas_ptr)px, (las_ptr)(sx + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  const int ip = lane & 15, cb = ((lane >> 4) & 1) * 16, tq = ip >> 2, tp = ip & 3;
+  // per-lane byte offsets of the transposed reads (k-step / q4 row bases are immediates)
+  uint32_t offA[4], offB[2];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) offA[i] = (8 * lh + tq) * ROWB + ((((wr * 128 + i * 32 + cb + 4 * tp) * 2)) ^ (tq << 6));
+#pragma unroll
+  for (int j = 0; j < 2; ++j) offB[j] = TILEB + (8 * lh + tq) * ROWB + ((((wc * 64 + j * 32 + cb + 4 * tp) * 2)) ^ (tq << 6));
+
+  typedef u32x2 frag_half;
+  frag_half fa[2][4][2], fb[2][2][2];                           // [pipeline slot][tile][lo/hi]
+#define TN_READS(slot, ks, base)                                                                                   \
+  OSUF_TR_READ(fa[slot][0][0], base + offA[0], (ks) * 16 * 512); OSUF_TR_READ(fa[slot][0][1], base + offA[0], ((ks) * 16 + 4) * 512); \
+  OSUF_TR_READ(fa[slot][1][0], base + offA[1], (ks) * 16 * 512); OSUF_TR_READ(fa[slot][1][1], base + offA[1], ((ks) * 16 + 4) * 512); \
+  OSUF_TR_READ(fa[slot][2][0], base + offA[2], (ks) * 16 * 512); OSUF_TR_READ(fa[slot][2][1], base + offA[2], ((ks) * 16 + 4) * 512); \
+  OSUF_TR_READ(fa[slot][3][0], base + offA[3], (ks) * 16 * 512); OSUF_TR_READ(fa[slot][3][1], base + offA[3], ((ks) * 16 + 4) * 512); \
+  OSUF_TR_READ(fb[slot][0][0], base + offB[0], (ks) * 16 * 512); OSUF_TR_READ(fb[slot][0][1], base + offB[0], ((ks) * 16 + 4) * 512); \
+  OSUF_TR_READ(fb[slot][1][0], base + offB[1], (ks) * 16 * 512); OSUF_TR_READ(fb[slot][1][1], base + offB[1], ((ks) * 16 + 4) * 512);
+#define TN_WAIT(slot, n)                                                                                          \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                        \
+               : "+v"(fa[slot][0][0]), "+v"(fa[slot][0][1]), "+v"(fa[slot][1][0]), "+v"(fa[slot][1][1]), "+v"(fa[slot][2][0]),  \
+                 "+v"(fa[slot][2][1]), "+v"(fa[slot][3][0]), "+v"(fa[slot][3][1]), "+v"(fb[slot][0][0]), "+v"(fb[slot][0][1]),  \
+                 "+v"(fb[slot][1][0]), "+v"(fb[slot][1][1]));                                                     \
+  __builtin_amdgcn_sched_barrier(0);
+#define TN_MFMA(slot)                                                                                             \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                   \
+    u32x4 va = {fa[slot][i][0][0], fa[slot][i][0][1], fa[slot][i][1][0], fa[slot][i][1][1]};                       \
+    u32x4 vb = {fb[slot][j][0][0], fb[slot][j][0][1], fb[slot][j][1][0], fb[slot][j][1][1]};                       \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, vb), acc[i][j], 0, 0, 0); \
+  }
+
+  issue(m_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  for (int mb = m_begin; mb < m_end; mb += BKM, buf ^= 1) {
+    const bool more = mb + BKM < m_end;
+    if (more) issue(mb + BKM, buf ^ 1);
+    const uint32_t base = lds0 + buf * 2 * TILEB;
+    TN_READS(0, 0, base)
+    TN_READS(1, 1, base)
+    TN_WAIT(0, 12)
+    TN_MFMA(0)
+    TN_READS(0, 2, base)
+    TN_WAIT(1, 12)
+    TN_MFMA(1)
+    TN_READS(1, 3, base)
+    TN_WAIT(0, 12)
+    TN_MFMA(0)
+    TN_WAIT(1, 0)
+    TN_MFMA(1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#undef TN_READS
+#undef TN_WAIT
+#undef TN_MFMA
+
+  if (g.ws) {
+    // partial tile of this m-split: plain 128-B-segment stores (5x the fp32-atomic rate), summed by wgrad_reduce_kernel
+    float* out = g.ws + ((long)split * g.taps + t) * g.N1 * g.N2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n2 = n2_0 + wc * 64 + j * 32 + lr;
+        if (n2 < g.N2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n1 = n1_0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (n1 < g.N1) out[(long)n1 * g.N2 + n2] = acc[i][j][r];
+          }
+        }
+      }
+    return;
+  }
+  float* dW = g.dW + (long)t * g.tapstride;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n2 = n2_0 + wc * 64 + j * 32 + lr;
+      if (n2 < g.N2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n1 = n1_0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (n1 < g.N1) atomic_add_f32(dW + (long)n1 * g.ldw + n2, acc[i][j][r]);
+        }
+      }
+    }
+}
+
+// dW[i] += sum_s ws[s][i]   (deterministic second stage of the split wgrad)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* dW, long n, int splits) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 a = reinterpret_cast<const f32x4*>(ws)[i];
+    for (int sidx = 1; sidx < splits; ++sidx) {
+      f32x4 b = reinterpret_cast<const f32x4*>(ws + (long)sidx * n)[i];
+      a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+    }
+    f32x4 d = reinterpret_cast<f32x4*>(dW)[i];
+    d[0] += a[0]; d[1] += a[1]; d[2] += a[2]; d[3] += a[3];
+    reinterpret_cast<f32x4*>(dW)[i] = d;
+  }
+}
+
 // column sums: out[n] += sum_m Y[m][n]   (bias gradients)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* Y, long ldy, int M, int N, float* out, int rows_per_block) {
@@ -793,7 +974,8 @@ extern "C" int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, l
     const int lds_big = 2 * kBigStage + 1024;
     static bool big_attr = false;
     if (!big_attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big); big_attr = true; }
-    hipLaunchKernelGGL(gemm_nt_big_kernel<bf16_t>, dim3((int)big_tiles), dim3(512), lds_big, stream, g);
+    const long tm = (M + kBig - 1) / kBig, tn = (N + kBig - 1) / kBig;
+    hipLaunchKernelGGL(gemm_nt_big_kernel<bf16_t>, dim3((int)(((tm + 7) / 8) * 8 * tn)), dim3(512), lds_big, stream, g);
   } else if (regstage) {
     if (dtype == OSUF_DT_BF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16_t>, dim3(grid), dim3(256), lds, stream, g);
     else hipLaunchKernelGGL(gemm_nt_kernel<float>, dim3(grid), dim3(256), lds, stream, g);
@@ -804,15 +986,61 @@ extern "C" int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, l
   return osuf_launch_status();
 }
 
+// split plan of the 256x256 wgrad kernel: rows of m per split and number of splits (one workgroup per CU, ~1.25 rounds)
+static bool tn_big_plan(int dtype, int M, int N1, int N2, int taps, int* rows_out, int* splits_out) {
+  const char* bigenv = getenv("OSUF_GEMM_BIG_MIN_TILES");
+  const bool forced = bigenv && atol(bigenv) == 1, off = bigenv && atol(bigenv) <= 0;
+  if (dtype != OSUF_DT_BF16 || off || !(forced || (N1 >= 192 && N2 >= 192))) return false;
+  const int btiles = ((N1 + kBig - 1) / kBig) * ((N2 + kBig - 1) / kBig);
+  int sp = (256 + btiles * taps / 2) / (btiles * taps);        // one workgroup per CU: about one round of the 256 CUs
+  if (sp < 1) sp = 1;
+  int rows = (M + sp - 1) / sp;
+  rows = ((rows + 63) / 64) * 64;
+  *rows_out = rows;
+  *splits_out = (M + rows - 1) / rows;
+  return true;
+}
+
+// bytes of fp32 workspace that let osuf_gemm_tn avoid atomics for this shape (0: the atomic path is used anyway)
+extern "C" long osuf_gemm_tn_workspace_bytes(int dtype, int M, int N1, int N2, int taps) {
+  int rows, sp;
+  if (M <= 0 || N1 <= 0 || N2 <= 0 || taps <= 0 || !tn_big_plan(dtype, M, N1, N2, taps, &rows, &sp)) return 0;
+  if ((N1 * (long)N2 * taps) % 4) return 0;
+  return (long)sp * taps * N1 * N2 * (long)sizeof(float);
+}
+
 extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, long tapstride,
                             int M, int N1, int N2, int taps, int Lin, int Lout, int stride, int pad, int mode,
-                            int splits, hipStream_t stream) {
+                            int splits, float* workspace, long workspace_bytes, hipStream_t stream) {
   const int epc = dtype == OSUF_DT_BF16 ? 8 : 4;
   if (dtype != OSUF_DT_BF16 && dtype != OSUF_DT_F32) return OSUF_EUNSUPPORTED;
   if (M <= 0 || N1 <= 0 || N2 <= 0 || taps <= 0 || Lout <= 0 || Lin <= 0 || M % Lout) return OSUF_EINVAL;
   if (N1 % epc || N2 % epc || ldy % epc || ldx % epc) return OSUF_EINVAL;
   if (!aligned16(dY) || !aligned16(X)) return OSUF_EINVAL;
   const int bkm = dtype == OSUF_DT_BF16 ? 64 : 32;
+  {
+    int rows, sp;
+    if (splits <= 0 && tn_big_plan(dtype, M, N1, N2, taps, &rows, &sp)) {
+      WgradArgs gb;
+      gb.dY = dY; gb.X = X; gb.dW = dW; gb.ldy = ldy; gb.ldx = ldx; gb.ldw = ldw; gb.tapstride = tapstride;
+      gb.M = M; gb.N1 = N1; gb.N2 = N2; gb.taps = taps; gb.rm = RowMap{Lin, Lout, stride, pad, mode};
+      gb.rows_per_split = rows;
+      const long n = (long)taps * N1 * N2;
+      const bool dense = ldw == N2 && (taps == 1 || tapstride == (long)N1 * N2) && n % 4 == 0 && aligned16(dW);
+      gb.ws = (workspace && dense && aligned16(workspace) && workspace_bytes >= (long)sp * n * (long)sizeof(float)) ? workspace : nullptr;
+      const int btiles = ((N1 + kBig - 1) / kBig) * ((N2 + kBig - 1) / kBig);
+      const int lds_big = 2 * 65536;
+      static bool attr = false;
+      if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big); attr = true; }
+      hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(((sp * btiles + 7) / 8) * 8 * taps), dim3(512), lds_big, stream, gb);
+      if (gb.ws) {
+        long blocks = (n / 4 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, gb.ws, dW, n, sp);
+      }
+      return osuf_launch_status();
+    }
+  }
   const int tiles = ((N1 + kTile - 1) / kTile) * ((N2 + kTile - 1) / kTile);
   if (splits <= 0) {                                  // aim at ~3 workgroups per CU
     splits = (768 + tiles * taps - 1) / (tiles * taps);
@@ -824,6 +1052,7 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
   g.dY = dY; g.X = X; g.dW = dW; g.ldy = ldy; g.ldx = ldx; g.ldw = ldw; g.tapstride = tapstride;
   g.M = M; g.N1 = N1; g.N2 = N2; g.taps = taps; g.rm = RowMap{Lin, Lout, stride, pad, mode};
   g.rows_per_split = rows;
+  g.ws = nullptr;
   const int lds = 4 * 16384;
   if (dtype == OSUF_DT_BF16) {
     hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(tiles, taps, splits), dim3(256), lds, stream, g);

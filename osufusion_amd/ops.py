@@ -122,8 +122,25 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, *, taps: int = 1, lin: Optional[i
     assert dy.dtype == x.dtype and Mx // lin == M // lout
     if out is None:
         out = torch.zeros((taps, N1, N2), dtype=torch.float32, device=dy.device)
-    call("osuf_gemm_tn", dt_of(dy), _p(dy), ldy, _p(x), ldx, _p(out), N2, N1 * N2, M, N1, N2, taps, lin, lout, stride, pad, mode, 0, _stream())
+    need = _lib.load().osuf_gemm_tn_workspace_bytes(dt_of(dy), M, N1, N2, taps)
+    ws = _workspace(need, dy.device) if need > 0 else None
+    call("osuf_gemm_tn", dt_of(dy), _p(dy), ldy, _p(x), ldx, _p(out), N2, N1 * N2, M, N1, N2, taps, lin, lout, stride, pad, mode, 0,
+         _p(ws), need if ws is not None else 0, _stream())
     return out
+
+
+_WS = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Persistent fp32 scratch for split-wgrad partial tiles (grown geometrically, one per device; kernels on one stream
+    are ordered, so consecutive wgrads can share it)."""
+    key = str(device)
+    cur = _WS.get(key)
+    if cur is None or cur.numel() * 4 < nbytes:
+        cur = torch.empty(max(nbytes // 4, 1 << 24) * 5 // 4, dtype=torch.float32, device=device)
+        _WS[key] = cur
+    return cur
 
 
 def colsum(y: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:

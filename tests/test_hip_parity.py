@@ -128,11 +128,13 @@ def test_big_tile_gemm_kernel(monkeypatch, kind, k, L):
         stats = torch.zeros(B, 2, dtype=torch.float64, device=DEV)
         y, pre = Fn.conv_forward(x, w, bias, Fn.PackCache(), kind, None, act=1, residual=res, rscale=rscale, stats=stats, want_pre=True)
         dx = Fn.conv_dgrad(y, w, Fn.PackCache(), kind, L, residual=x)
-        outs.append((y.float(), pre.float(), stats.clone(), dx.float()))
+        dw = Fn.conv_wgrad(res, x, w, kind)                      # 256x256 LDS-DMA wgrad kernel when forced
+        outs.append((y.float(), pre.float(), stats.clone(), dx.float(), dw.float()))
     monkeypatch.delenv("OSUF_GEMM_BIG_MIN_TILES")
-    (y0, p0, s0, d0), (y1, p1, s1, d1) = outs
+    (y0, p0, s0, d0, w0), (y1, p1, s1, d1, w1) = outs
     assert torch.equal(y0, y1) and torch.equal(p0, p1) and torch.equal(d0, d1)
     assert torch.allclose(s0, s1, rtol=1e-6)
+    assert relmax(w1, w0) < 1e-5                                 # fp32 atomics: same products, different summation order
     xq, wq = x.float(), w.to(torch.bfloat16).float()
     if kind == "same":
         ref = F.conv1d(xq.permute(0, 2, 1), wq, bias, padding=k // 2)

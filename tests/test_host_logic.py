@@ -231,7 +231,7 @@ def test_ddim_schedule_known_answers():
 def _header_decls():
     src = (ROOT / "include" / "osufusion_hip.h").read_text()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return re.findall(r"\bint\s+(osuf_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+    return re.findall(r"\b(?:int|long)\s+(osuf_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S)
 
 
 def test_capi_exports_every_declared_symbol():
