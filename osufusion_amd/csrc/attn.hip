@@ -11,6 +11,7 @@
 // (key-stationary: a wave owns 32 keys, dK^T/dV^T stay in registers while it sweeps heads x query blocks).
 #include "common.hpp"
 #include <type_traits>
+#include <stdlib.h>
 
 static constexpr int D = 64;                      // head dim (bytes per tile row = 128)
 static constexpr float kLog2e = 1.4426950408889634f;
@@ -81,24 +82,32 @@ struct AttnArgs {
   float scale;
 };
 
-// cooperative K/V tile stage: 512 threads, one 16-B chunk of K and one of V each (64 keys x 128 B)
+// cooperative K/V tile stage: NT threads move one 64-key tile (64 x 128 B of K and of V = 512 + 512 16-B chunks)
+template <int NT>
 struct KVStage {
-  u32x4 rk, rv;
+  static constexpr int PER = 512 / NT;
+  u32x4 rk[PER], rv[PER];
   __device__ __forceinline__ void load(const AttnArgs& a, int b, int key0, int tid) {
-    const int row = tid >> 3, chunk = tid & 7;
-    const int key = key0 + row;
-    u32x4 z = {0u, 0u, 0u, 0u};
-    rk = z; rv = z;
-    if (key < a.N) {
-      const long m = (long)b * a.N + key;
-      rk = *reinterpret_cast<const u32x4*>(a.k + m * a.ldk + chunk * 8);
-      rv = *reinterpret_cast<const u32x4*>(a.v + m * a.ldv + chunk * 8);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int cid = tid + i * NT, row = cid >> 3, chunk = cid & 7;
+      const int key = key0 + row;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      rk[i] = z; rv[i] = z;
+      if (key < a.N) {
+        const long m = (long)b * a.N + key;
+        rk[i] = *reinterpret_cast<const u32x4*>(a.k + m * a.ldk + chunk * 8);
+        rv[i] = *reinterpret_cast<const u32x4*>(a.v + m * a.ldv + chunk * 8);
+      }
     }
   }
   __device__ __forceinline__ void store(char* ks, char* vs, int tid) const {
-    const int row = tid >> 3, chunk = tid & 7;
-    *reinterpret_cast<u32x4*>(ks + tile_off(row, chunk * 16)) = rk;
-    *reinterpret_cast<u32x4*>(vs + tile_off(row, chunk * 16)) = rv;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int cid = tid + i * NT, row = cid >> 3, chunk = cid & 7;
+      *reinterpret_cast<u32x4*>(ks + tile_off(row, chunk * 16)) = rk[i];
+      *reinterpret_cast<u32x4*>(vs + tile_off(row, chunk * 16)) = rv[i];
+    }
   }
 };
 
@@ -107,13 +116,14 @@ struct KVStage {
 // (A two-wave-group variant skewed by half a tile with LDS-DMA staging was measured at 590-605 TFLOP/s against 803 for
 //  this single-phase loop -- two barriers per tile and the serial MFMA -> max -> exp chain cost more than the overlap won.)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void mqa_fwd_kernel(AttnArgs a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void mqa_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][K 8K | V 8K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.y;
   const int nqb = (a.N + 31) >> 5;
-  const int vb = blockIdx.x * 8 + wave;
+  const int vb = blockIdx.x * NW + wave;
   const bool active = vb < nqb * a.H;
   const int h = active ? vb % a.H : 0, pb = active ? vb / a.H : 0;
   const int qrow = pb * 32 + lr;
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(512) void mqa_fwd_kernel(AttnArgs a) {
 
   const LaneOffs lo(lane);
   const int ntiles = (a.N + 63) >> 6;
-  KVStage st;
+  KVStage<NW * 64> st;
   st.load(a, b, 0, tid);
   st.store(smem, smem + 8192, tid);
   __syncthreads();
@@ -234,13 +244,14 @@ __global__ __launch_bounds__(512) void mqa_fwd_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------------
 // backward, dQ: query-stationary.  dQ^T[d][q] = sum_key K^T[d][key] * dS^T[key][q]
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void mqa_bwd_dq_kernel(AttnArgs a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void mqa_bwd_dq_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.y;
   const int nqb = (a.N + 31) >> 5;
-  const int vb = blockIdx.x * 8 + wave;
+  const int vb = blockIdx.x * NW + wave;
   const bool active = vb < nqb * a.H;
   const int h = active ? vb % a.H : 0, pb = active ? vb / a.H : 0;
   const int qrow = pb * 32 + lr;
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_dq_kernel(AttnArgs a) {
 
   const LaneOffs lo(lane);
   const int ntiles = (a.N + 63) >> 6;
-  KVStage st;
+  KVStage<NW * 64> st;
   st.load(a, b, 0, tid);
   st.store(smem, smem + 8192, tid);
   __syncthreads();
@@ -323,13 +334,21 @@ __global__ __launch_bounds__(512) void mqa_bwd_dq_kernel(AttnArgs a) {
 // backward, dK/dV: key-stationary.  A wave owns 32 keys; the workgroup (8 waves = 256 keys) sweeps every
 // (head, 32-query block) pair, staging Q / dO / lse / delta of the pair in LDS for all waves.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void mqa_bwd_dkv_kernel(AttnArgs a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void mqa_bwd_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][Q 4K | dO 4K | lse 128 | delta 128]
   constexpr int kStage = 4096 + 4096 + 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.y;
-  const int key = blockIdx.x * 256 + wave * 32 + lr;
+  // XCD-aware order (speed only): every key block of a sample sweeps the same Q / dO / lse / delta; block ids are dealt
+  // round-robin over the 8 XCDs, so ids 8 apart share an L2.  PMC before this remap: 4.46 GB fetched per launch at
+  // N=4096 against 0.54 GB of distinct Q + dO bytes.
+  const int nkb = (a.N + 32 * NW - 1) / (32 * NW);
+  const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;
+  const int b = (qid / nkb) * 8 + xcd;
+  const int kb = qid % nkb;
+  if (b >= a.B) return;
+  const int key = kb * (32 * NW) + wave * 32 + lr;
   const bool kok = key < a.N;
   const float c = a.scale * kLog2e;
   const int nqb = (a.N + 31) >> 5;
@@ -352,18 +371,23 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
 
-  // stage loader: threads 0..255 -> Q chunk, 256..511 -> dO chunk; threads 0..31 lse, 32..63 delta
-  u32x4 rt; float rs = 0.f;
+  // stage loader: 512 16-B chunks per (head, query block): chunks 0..255 = Q tile, 256..511 = dO tile; threads 0..31 lse,
+  // 32..63 delta
+  constexpr int NT = NW * 64, PER = 512 / NT;
+  u32x4 rt[PER]; float rs = 0.f;
   auto load_stage = [&](int it) {
     const int h = it % a.H, pb = it / a.H;
-    const int t = tid & 255, row = t >> 3, chunk = t & 7;
-    const int qrow = pb * 32 + row;
-    u32x4 z = {0u, 0u, 0u, 0u};
-    rt = z;
-    if (qrow < a.N) {
-      const long m = (long)b * a.N + qrow;
-      rt = (tid < 256) ? *reinterpret_cast<const u32x4*>(a.q + m * a.ldq + h * D + chunk * 8)
-                       : *reinterpret_cast<const u32x4*>(a.dout + m * a.lddo + h * D + chunk * 8);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int cid = tid + i * NT, t = cid & 255, row = t >> 3, chunk = t & 7;
+      const int qrow = pb * 32 + row;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      rt[i] = z;
+      if (qrow < a.N) {
+        const long m = (long)b * a.N + qrow;
+        rt[i] = (cid < 256) ? *reinterpret_cast<const u32x4*>(a.q + m * a.ldq + h * D + chunk * 8)
+                            : *reinterpret_cast<const u32x4*>(a.dout + m * a.lddo + h * D + chunk * 8);
+      }
     }
     if (tid < 64) {
       const int qr = pb * 32 + (tid & 31);
@@ -374,8 +398,11 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_kernel(AttnArgs a) {
   };
   auto store_stage = [&](int buf) {
     char* base = smem + buf * kStage;
-    const int t = tid & 255, row = t >> 3, chunk = t & 7;
-    *reinterpret_cast<u32x4*>(base + (tid < 256 ? 0 : 4096) + tile_off(row, chunk * 16)) = rt;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int cid = tid + i * NT, t = cid & 255, row = t >> 3, chunk = t & 7;
+      *reinterpret_cast<u32x4*>(base + (cid < 256 ? 0 : 4096) + tile_off(row, chunk * 16)) = rt[i];
+    }
     if (tid < 64) reinterpret_cast<float*>(base + 8192)[tid] = rs;
   };
 
@@ -541,6 +568,10 @@ static inline int ew_grid(long total_threads) {
   return (int)blocks;
 }
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static int attn_waves() {                        // waves per workgroup (A/B knob OSUF_ATTN_WAVES=4|8; measured round 1 at N=4096:
+  const char* e = getenv("OSUF_ATTN_WAVES");     // 8 waves 814 / 946 / 846 TFLOP/s (fwd / dQ / dKdV) vs 4 waves 730 / 832 / 587)
+  return (e && atoi(e) == 4) ? 4 : 8;
+}
 
 extern "C" int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
                             float* lse2, int B, int H, int N, int head_dim, float scale, hipStream_t stream) {
@@ -550,7 +581,8 @@ extern "C" int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, co
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
   a.o = o; a.ldo = ldo; a.o_is_f32 = o_dtype == OSUF_DT_F32; a.lse2 = lse2; a.B = B; a.H = H; a.N = N; a.scale = scale;
   const int nvb = ((N + 31) / 32) * H;
-  hipLaunchKernelGGL(mqa_fwd_kernel, dim3((nvb + 7) / 8, B), dim3(512), 32768, stream, a);
+  if (attn_waves() == 4) hipLaunchKernelGGL(mqa_fwd_kernel<4>, dim3((nvb + 3) / 4, B), dim3(256), 32768, stream, a);
+  else hipLaunchKernelGGL(mqa_fwd_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768, stream, a);
   return osuf_launch_status();
 }
 
@@ -590,7 +622,8 @@ extern "C" int osuf_mqa_bwd_dq(const void* q, long ldq, const void* k, long ldk,
   if (lddq % 4 || !al16(dq)) return OSUF_EINVAL;
   a.dq = dq; a.lddq = lddq;
   const int nvb = ((N + 31) / 32) * H;
-  hipLaunchKernelGGL(mqa_bwd_dq_kernel, dim3((nvb + 7) / 8, B), dim3(512), 32768, stream, a);
+  if (attn_waves() == 4) hipLaunchKernelGGL(mqa_bwd_dq_kernel<4>, dim3((nvb + 3) / 4, B), dim3(256), 32768, stream, a);
+  else hipLaunchKernelGGL(mqa_bwd_dq_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768, stream, a);
   return osuf_launch_status();
 }
 
@@ -603,7 +636,9 @@ extern "C" int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk
   if (rc) return rc;
   if (lddk % 4 || !al16(dk) || !al16(dv)) return OSUF_EINVAL;
   a.dk = dk; a.dv = dv; a.lddk = lddk;
-  hipLaunchKernelGGL(mqa_bwd_dkv_kernel, dim3((N + 255) / 256, B), dim3(512), 2 * (4096 + 4096 + 256), stream, a);
+  const int b8 = (B + 7) / 8 * 8;
+  if (attn_waves() == 4) hipLaunchKernelGGL(mqa_bwd_dkv_kernel<4>, dim3(((N + 127) / 128) * b8), dim3(256), 2 * (4096 + 4096 + 256), stream, a);
+  else hipLaunchKernelGGL(mqa_bwd_dkv_kernel<8>, dim3(((N + 255) / 256) * b8), dim3(512), 2 * (4096 + 4096 + 256), stream, a);
   return osuf_launch_status();
 }
 

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void wcolsum_kernel(const T* a, long lda, cons
   }
 }
 
-// out = h * gate[b][:] + res
+// out = h * gate[b][:] + res        (res may be null: out = h * gate)
 template <typename T>
 __global__ __launch_bounds__(256) void gate_residual_kernel(const T* h, long ldh, const float* gate, const T* res, long ldr,
                                                             T* out, long ldo, int M, int C, int L) {
@@ -428,9 +428,14 @@ __global__ __launch_bounds__(256) void gate_residual_kernel(const T* h, long ldh
     float v[8], g[8], r[8];
     load8(h + (long)m * ldh + c, v);
     load8(gate + (long)b * C + c, g);
-    load8(res + (long)m * ldr + c, r);
+    if (res) {
+      load8(res + (long)m * ldr + c, r);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = v[e] * g[e] + r[e];
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * g[e] + r[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= g[e];
+    }
     store8(out + (long)m * ldo + c, v);
   }
 }
@@ -596,7 +601,7 @@ extern "C" int osuf_wcolsum(int dtype, const void* a, long lda, const void* bmul
 
 extern "C" int osuf_gate_residual(int dtype, const void* h, long ldh, const float* gate, const void* res, long ldr, void* out, long ldo,
                                   int M, int C, int L, hipStream_t stream) {
-  if (bad_c(C) || M <= 0 || L <= 0 || M % L || ldh % 8 || ldr % 8 || ldo % 8) return OSUF_EINVAL;
+  if (bad_c(C) || M <= 0 || L <= 0 || M % L || ldh % 8 || (res && ldr % 8) || ldo % 8) return OSUF_EINVAL;
   DISPATCH_T(dtype, hipLaunchKernelGGL(gate_residual_kernel<T>, dim3(ew_grid((long)M * (C / 8))), dim3(256), 0, stream, (const T*)h, ldh,
                                        gate, (const T*)res, ldr, (T*)out, ldo, M, C, L));
   return osuf_launch_status();

@@ -219,8 +219,7 @@ class GateResFn(torch.autograd.Function):
         B, L, C = h.shape
         dout = _rc(dout)
         dgate = ops.wcolsum(dout, h, None, B, L)
-        zero = torch.zeros_like(dout)
-        dh = ops.gate_residual(dout, gate, zero, L)                 # dout * gate
+        dh = ops.gate_residual(dout, gate, None, L)                 # dout * gate
         return dh, dgate, dout
 
 
@@ -240,7 +239,7 @@ class GateResConvFn(torch.autograd.Function):
         B, L, C = h.shape
         dout = _rc(dout)
         dgate = ops.wcolsum(dout, h, None, B, L)
-        dh = ops.gate_residual(dout, gate, torch.zeros_like(dout), L)
+        dh = ops.gate_residual(dout, gate, None, L)
         dx = conv_dgrad(dout, w, ctx.cache, "same", L)
         dw = conv_wgrad(dout, x, w, "same")
         db = ops.colsum(dout)

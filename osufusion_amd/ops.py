@@ -217,10 +217,11 @@ def wcolsum(a: torch.Tensor, bmul: Optional[torch.Tensor], w: Optional[torch.Ten
     return out
 
 
-def gate_residual(h: torch.Tensor, gate: torch.Tensor, res: torch.Tensor, L: int) -> torch.Tensor:
+def gate_residual(h: torch.Tensor, gate: torch.Tensor, res: Optional[torch.Tensor], L: int) -> torch.Tensor:
+    """out = h * gate[b] (+ res)."""
     M, C, ld = _rows(h)
     out = torch.empty(h.shape, dtype=h.dtype, device=h.device)
-    call("osuf_gate_residual", dt_of(h), _p(h), ld, _p(gate), _p(res), _rows(res)[2], _p(out), C, M, C, L, _stream())
+    call("osuf_gate_residual", dt_of(h), _p(h), ld, _p(gate), _p(res), _rows(res)[2] if res is not None else 0, _p(out), C, M, C, L, _stream())
     return out
 
 

@@ -14,7 +14,7 @@ def timeit(fn, iters=10):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
 print(f"{'N':>6s} {'fwd ms':>8s} {'TF/s':>6s} | {'dq ms':>8s} {'TF/s':>6s} | {'dkv ms':>8s} {'TF/s':>6s}")
-for N in (4096, 2048, 1024, 512):
+for N in ([int(a) for a in sys.argv[1:]] or [4096, 2048, 1024, 512]):
     qkv = torch.randn(B, N, (H + 2) * D, device=dev).to(torch.bfloat16)
     o, lse = ops.mqa_fwd(qkv, B, N, H, D, torch.bfloat16, D ** -0.5)
     do = torch.randn(B, N, H * D, device=dev).to(torch.bfloat16)
