@@ -117,7 +117,7 @@ struct KVStage {
 //  this single-phase loop -- two barriers per tile and the serial MFMA -> max -> exp chain cost more than the overlap won.)
 // ------------------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void mqa_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][K 8K | V 8K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -130,14 +130,17 @@ __global__ __launch_bounds__(NW * 64) void mqa_fwd_kernel(AttnArgs a) {
   const bool qok = active && qrow < a.N;
   const float c = a.scale * kLog2e;
 
-  bf16x8 qf[4];
+  // Q tile of this wave: 32 rows x 128 B in a wave-private LDS slice behind the K/V ring (re-read once per k-step).  Keeping
+  // the 16 fragment registers live across the loop pushed the kernel over 128 VGPRs; at <= 128 four waves per SIMD fit
+  // (two workgroups per CU): measured 812 -> ~890 TFLOP/s.
+  char* qtile = smem + 32768 + wave * 4096;
   {
     const bf16_t* qp = a.q + ((long)b * a.N + qrow) * a.ldq + h * D;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       u32x4 z = {0u, 0u, 0u, 0u};
       if (qok) z = *reinterpret_cast<const u32x4*>(qp + 16 * ks + 8 * lh);
-      qf[ks] = __builtin_bit_cast(bf16x8, z);
+      *reinterpret_cast<u32x4*>(qtile + tile_off(lr, (2 * ks + lh) * 16)) = z;
     }
   }
   f32x16 o[2];
@@ -162,12 +165,15 @@ __global__ __launch_bounds__(NW * 64) void mqa_fwd_kernel(AttnArgs a) {
     // S^T = K Q^T  (two 32-key tiles)
     f32x16 s[2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(ks_, lo, ks, kt), qf[ks], s[kt], 0, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 qf = lds_row_frag(qtile, lo, ks, 0);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(ks_, lo, ks, kt), qf, s[kt], 0, 0, 0);
     }
     if constexpr (MASK) {
 #pragma unroll
@@ -581,8 +587,8 @@ extern "C" int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, co
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
   a.o = o; a.ldo = ldo; a.o_is_f32 = o_dtype == OSUF_DT_F32; a.lse2 = lse2; a.B = B; a.H = H; a.N = N; a.scale = scale;
   const int nvb = ((N + 31) / 32) * H;
-  if (attn_waves() == 4) hipLaunchKernelGGL(mqa_fwd_kernel<4>, dim3((nvb + 3) / 4, B), dim3(256), 32768, stream, a);
-  else hipLaunchKernelGGL(mqa_fwd_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768, stream, a);
+  if (attn_waves() == 4) hipLaunchKernelGGL(mqa_fwd_kernel<4>, dim3((nvb + 3) / 4, B), dim3(256), 32768 + 4 * 4096, stream, a);
+  else hipLaunchKernelGGL(mqa_fwd_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768 + 8 * 4096, stream, a);
   return osuf_launch_status();
 }
 
