@@ -42,14 +42,16 @@ int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, long ldw, lo
                  int M, int N, int K, int taps, int Lin, int Lout, int stride, int pad, int mode, int act,
                  hipStream_t stream);
 
-/* dW[t][n1][n2] += sum_m dY[m][n1] * X[rowmap(m,t)][n2]   (dW must be initialised by the caller)
+/* dW (+)= sum_m dY[m][n1] * X[rowmap(m,t)][n2].  out_layout 0: dW[t][n1][n2] with row stride ldw and tap stride tapstride;
+ * out_layout 1: dense dW[n1][n2][t], i.e. torch's (Cout, Cin, k) Conv1d weight layout, so the gradient can be accumulated
+ * straight into the parameter's .grad.  accumulate 1: add into dW; 0: overwrite (no zero-init needed by the caller).
  * The reduction over m is split across workgroups.  With a caller-provided fp32 `workspace` of at least
  * osuf_gemm_tn_workspace_bytes(...) bytes the partial tiles are written with plain stores and summed by a second kernel
  * (deterministic); without it (NULL / too small / shape not eligible) partial sums are added with fp32 atomics.
  * replaces: autograd's weight-gradient of every Conv1d / Linear listed above. */
 int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, long tapstride,
                  int M, int N1, int N2, int taps, int Lin, int Lout, int stride, int pad, int mode,
-                 int splits, float* workspace, long workspace_bytes, hipStream_t stream);
+                 int splits, int out_layout, int accumulate, float* workspace, long workspace_bytes, hipStream_t stream);
 long osuf_gemm_tn_workspace_bytes(int dtype, int M, int N1, int N2, int taps);
 
 /* out[n] += sum_m Y[m][n]     replaces: autograd's bias-gradient of Conv1d / Linear. */

@@ -571,6 +571,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(GemmArgs g) {
 struct WgradArgs {
   const void* dY; const void* X; float* dW;
   float* ws;                       // optional [splits][taps][N1][N2] partial tiles (plain stores) instead of atomics
+  long es;                         // element stride of n2 in dW (1, or `taps` for torch's (Cout, Cin, k) weight layout)
   long ldy, ldx, ldw, tapstride;
   int M, N1, N2, taps;
   RowMap rm;
@@ -719,7 +720,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           int n1 = n1_0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (n1 < g.N1) atomic_add_f32(dW + (long)n1 * g.ldw + n2, acc[i][j][r]);
+          if (n1 < g.N1) atomic_add_f32(dW + (long)n1 * g.ldw + (long)n2 * g.es, acc[i][j][r]);
         }
       }
     }
@@ -879,24 +880,48 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(WgradArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n1 = n1_0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (n1 < g.N1) atomic_add_f32(dW + (long)n1 * g.ldw + n2, acc[i][j][r]);
+          if (n1 < g.N1) atomic_add_f32(dW + (long)n1 * g.ldw + (long)n2 * g.es, acc[i][j][r]);
         }
       }
     }
 }
 
-// dW[i] += sum_s ws[s][i]   (deterministic second stage of the split wgrad)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* dW, long n, int splits) {
-  const long n4 = n >> 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    f32x4 a = reinterpret_cast<const f32x4*>(ws)[i];
-    for (int sidx = 1; sidx < splits; ++sidx) {
-      f32x4 b = reinterpret_cast<const f32x4*>(ws + (long)sidx * n)[i];
-      a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+// deterministic second stage of the split wgrad: dW (+)= sum_s ws[s][t][i], i = n1*N2 + n2.
+// LAYOUT 0: dW[t][i] (the kernel's own order)   LAYOUT 1: dW[i][t] = torch's (Cout, Cin, k) conv weight layout -- the permute
+// is free here: a thread owns one i and writes its `taps` values contiguously.
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* dW, long n12, int taps, int splits, int accumulate) {
+  if constexpr (LAYOUT == 0) {
+    const long n = n12 * taps, n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+      f32x4 a = reinterpret_cast<const f32x4*>(ws)[i];
+      for (int sidx = 1; sidx < splits; ++sidx) {
+        f32x4 b = reinterpret_cast<const f32x4*>(ws + (long)sidx * n)[i];
+        a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+      }
+      if (accumulate) {
+        f32x4 d = reinterpret_cast<f32x4*>(dW)[i];
+        a[0] += d[0]; a[1] += d[1]; a[2] += d[2]; a[3] += d[3];
+      }
+      reinterpret_cast<f32x4*>(dW)[i] = a;
     }
-    f32x4 d = reinterpret_cast<f32x4*>(dW)[i];
-    d[0] += a[0]; d[1] += a[1]; d[2] += a[2]; d[3] += a[3];
-    reinterpret_cast<f32x4*>(dW)[i] = d;
+  } else {
+    // a thread owns 4 consecutive i: float4 loads of the partials (16 B/lane), then 4*taps contiguous outputs
+    const long n = n12 * taps, q12 = n12 >> 2;            // n12 % 4 == 0 is guaranteed by the launcher
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < q12; q += (long)gridDim.x * blockDim.x) {
+      for (int t = 0; t < taps; ++t) {
+        f32x4 a = reinterpret_cast<const f32x4*>(ws + (long)t * n12)[q];
+        for (int sidx = 1; sidx < splits; ++sidx) {
+          f32x4 b = reinterpret_cast<const f32x4*>(ws + (long)sidx * n + (long)t * n12)[q];
+          a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float* dst = dW + (4 * q + e) * taps + t;
+          *dst = accumulate ? *dst + a[e] : a[e];
+        }
+      }
+    }
   }
 }
 
@@ -1011,7 +1036,11 @@ extern "C" long osuf_gemm_tn_workspace_bytes(int dtype, int M, int N1, int N2, i
 
 extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, long tapstride,
                             int M, int N1, int N2, int taps, int Lin, int Lout, int stride, int pad, int mode,
-                            int splits, float* workspace, long workspace_bytes, hipStream_t stream) {
+                            int splits, int out_layout, int accumulate, float* workspace, long workspace_bytes, hipStream_t stream) {
+  // out_layout 0: dW[t][n1][n2] with (ldw, tapstride) as given; 1: dense torch conv layout dW[n1][n2][t] (ldw/tapstride ignored)
+  long es = 1;
+  if (out_layout == 1) { ldw = (long)N2 * taps; tapstride = 1; es = taps; }
+  else if (out_layout != 0) return OSUF_EINVAL;
   const int epc = dtype == OSUF_DT_BF16 ? 8 : 4;
   if (dtype != OSUF_DT_BF16 && dtype != OSUF_DT_F32) return OSUF_EUNSUPPORTED;
   if (M <= 0 || N1 <= 0 || N2 <= 0 || taps <= 0 || Lout <= 0 || Lin <= 0 || M % Lout) return OSUF_EINVAL;
@@ -1026,17 +1055,21 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
       gb.M = M; gb.N1 = N1; gb.N2 = N2; gb.taps = taps; gb.rm = RowMap{Lin, Lout, stride, pad, mode};
       gb.rows_per_split = rows;
       const long n = (long)taps * N1 * N2;
-      const bool dense = ldw == N2 && (taps == 1 || tapstride == (long)N1 * N2) && n % 4 == 0 && aligned16(dW);
+      const bool dense = (out_layout == 1 && ((long)N1 * N2) % 4 == 0) || (out_layout == 0 && ldw == N2 && (taps == 1 || tapstride == (long)N1 * N2) && n % 4 == 0 && aligned16(dW));
       gb.ws = (workspace && dense && aligned16(workspace) && workspace_bytes >= (long)sp * n * (long)sizeof(float)) ? workspace : nullptr;
+      gb.es = es;
+      if (!gb.ws && !accumulate) (void)hipMemsetAsync(dW, 0, (size_t)n * sizeof(float), stream);    // atomic path needs zeros
       const int btiles = ((N1 + kBig - 1) / kBig) * ((N2 + kBig - 1) / kBig);
       const int lds_big = 2 * 65536;
       static bool attr = false;
       if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big); attr = true; }
       hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(((sp * btiles + 7) / 8) * 8 * taps), dim3(512), lds_big, stream, gb);
       if (gb.ws) {
-        long blocks = (n / 4 + 255) / 256;
+        const long n12 = (long)N1 * N2;
+        long blocks = ((out_layout == 1 ? n12 / 4 : n / 4) + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)blocks), dim3(256), 0, stream, gb.ws, dW, n, sp);
+        if (out_layout == 1) hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((int)blocks), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
+        else hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3((int)blocks), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
       }
       return osuf_launch_status();
     }
@@ -1053,6 +1086,11 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
   g.M = M; g.N1 = N1; g.N2 = N2; g.taps = taps; g.rm = RowMap{Lin, Lout, stride, pad, mode};
   g.rows_per_split = rows;
   g.ws = nullptr;
+  g.es = es;
+  if (!accumulate) {
+    if (out_layout == 0 && !(ldw == N2 && (taps == 1 || tapstride == (long)N1 * N2))) return OSUF_EINVAL;   // needs a dense dW to clear
+    (void)hipMemsetAsync(dW, 0, (size_t)taps * N1 * N2 * sizeof(float), stream);
+  }
   const int lds = 4 * 16384;
   if (dtype == OSUF_DT_BF16) {
     hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(tiles, taps, splits), dim3(256), lds, stream, g);

@@ -36,6 +36,44 @@ class PackCache:
         return t
 
 
+# ---- direct gradient accumulation ---------------------------------------------------------------------------
+# With a Trainer, every parameter owns a persistent fp32 .grad view into one flat buffer.  The backward kernels then add
+# straight into it (wgrad in torch's weight layout, bias / norm column sums by atomics) and return None to autograd, instead
+# of returning ~1.2 k fresh tensors that autograd adds one small kernel at a time (measured: 1,124 adds + ~700 fills = 11.6 ms
+# of a 300 ms step).  The reducer is told explicitly when a parameter's gradient is complete.
+_DIRECT = False
+_GRAD_DONE_CB = None
+
+
+def enable_direct_grads(flag: bool, done_callback=None) -> None:
+    global _DIRECT, _GRAD_DONE_CB
+    _DIRECT, _GRAD_DONE_CB = bool(flag), done_callback
+
+
+def grad_target(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if not _DIRECT or p is None or not p.is_leaf or not p.requires_grad:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or g.shape != p.shape or not g.is_contiguous():
+        return None
+    return g
+
+
+def grad_done(p: torch.Tensor) -> None:
+    if _GRAD_DONE_CB is not None:
+        _GRAD_DONE_CB(p)
+
+
+def _bias_grad(dy: torch.Tensor, bias: Optional[torch.Tensor], n: Optional[int] = None):
+    """Column sums of dy into bias.grad (direct) or a fresh tensor (returned)."""
+    tgt = grad_target(bias)
+    if tgt is not None:
+        ops.colsum(dy, n, out=tgt)
+        grad_done(bias)
+        return None
+    return ops.colsum(dy, n)
+
+
 def _rc(t: torch.Tensor) -> torch.Tensor:
     """Make a grad tensor kernel-consumable (last dim contiguous, dense rows, 16-B aligned)."""
     if t.stride(-1) != 1 or (t.dim() == 3 and t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1)) or t.data_ptr() % 16:
@@ -118,13 +156,20 @@ def conv_dgrad(dy, w, cache: PackCache, kind: str, Lin: int, residual=None, vp=N
     return ops.gemm_nt(dy, wp, None, lin=Lout, lout=Lin, residual=residual, out_shape=(B, Lin, Cin), **geom)
 
 
-def conv_wgrad(dy, x, w, kind: str):
-    """-> gradient tensor shaped like w."""
+def conv_wgrad(dy, x, w, kind: str, direct: bool = True):
+    """Weight gradient in w's own layout: added straight into w.grad (returns None) when direct accumulation is on and w is a
+    leaf parameter with a dense fp32 .grad; otherwise a fresh tensor shaped like w."""
     B, Lin, Cin = x.shape
-    k = w.shape[2] if w.dim() == 3 else 1
+    conv = w.dim() == 3
+    k = w.shape[2] if conv else 1
     Lout, stride, pad, mode = _conv_geom(kind, k, Lin)
-    g = ops.gemm_tn(dy, x, taps=k, lin=Lin, lout=Lout, stride=stride, pad=pad, mode=mode, n1=w.shape[0])   # [k][Cout][Cin]
-    return g[0] if w.dim() == 2 else g.permute(1, 2, 0)
+    tgt = grad_target(w) if direct else None
+    g = ops.gemm_tn(dy, x, taps=k, lin=Lin, lout=Lout, stride=stride, pad=pad, mode=mode, n1=w.shape[0], out=tgt, conv_layout=conv,
+                    accumulate=tgt is not None)
+    if tgt is not None:
+        grad_done(w)
+        return None
+    return g if conv else g[0]
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -135,6 +180,7 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x, w, bias, cache, kind, vp=None):
         ctx.save_for_backward(x, w)
         ctx.cache, ctx.kind, ctx.has_bias, ctx.vp = cache, kind, bias is not None, vp
+        ctx.bias_ref = bias                               # the Parameter itself (for direct .grad accumulation)
         return conv_forward(x, w, bias, cache, kind, vp)
 
     @staticmethod
@@ -143,7 +189,7 @@ class ConvFn(torch.autograd.Function):
         dy = _rc(dy)
         dx = conv_dgrad(dy, w, ctx.cache, ctx.kind, x.shape[1], vp=ctx.vp) if ctx.needs_input_grad[0] else None
         dw = conv_wgrad(dy, x, w, ctx.kind) if ctx.needs_input_grad[1] else None
-        db = ops.colsum(dy, w.shape[0]) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = _bias_grad(dy, ctx.bias_ref, w.shape[0]) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None, None, None
 
 
@@ -161,6 +207,7 @@ class BlockFn(torch.autograd.Function):
         h = ops.gn_apply(y, mr, gamma, beta, ssc, L)
         ctx.save_for_backward(x, w, y, mr, gamma, beta, ssc if ssc is not None else mr)
         ctx.cache, ctx.has_ss = cache, ss is not None
+        ctx.bias_ref = bias
         return h
 
     @staticmethod
@@ -168,10 +215,15 @@ class BlockFn(torch.autograd.Function):
         x, w, y, mr, gamma, beta, ss = ctx.saved_tensors
         ss = ss if ctx.has_ss else None
         L = x.shape[1]
-        dy, dgamma, dbeta, dss = ops.gn_bwd(_rc(dh), y, mr, gamma, beta, ss, L)
+        tg, tb = grad_target(gamma), grad_target(beta)
+        direct_norm = tg is not None and tb is not None
+        dy, dgamma, dbeta, dss = ops.gn_bwd(_rc(dh), y, mr, gamma, beta, ss, L, tg if direct_norm else None, tb if direct_norm else None)
+        if direct_norm:
+            grad_done(gamma); grad_done(beta)
+            dgamma = dbeta = None
         dx = conv_dgrad(dy, w, ctx.cache, "same", L) if ctx.needs_input_grad[0] else None
         dw = conv_wgrad(dy, x, w, "same")
-        db = ops.colsum(dy)
+        db = _bias_grad(dy, ctx.bias_ref)
         return dx, dw, db, dgamma, dbeta, dss, None
 
 
@@ -230,7 +282,7 @@ class GateResConvFn(torch.autograd.Function):
     def forward(ctx, h, gate, x, w, bias, cache):
         gate = gate.contiguous()
         ctx.save_for_backward(h, gate, x, w)
-        ctx.cache = cache
+        ctx.cache, ctx.bias_ref = cache, bias
         return conv_forward(x, w, bias, cache, "same", None, residual=h, rscale=gate)
 
     @staticmethod
@@ -242,7 +294,7 @@ class GateResConvFn(torch.autograd.Function):
         dh = ops.gate_residual(dout, gate, None, L)
         dx = conv_dgrad(dout, w, ctx.cache, "same", L)
         dw = conv_wgrad(dout, x, w, "same")
-        db = ops.colsum(dout)
+        db = _bias_grad(dout, ctx.bias_ref)
         return dh, dgate, dx, dw, db, None
 
 
@@ -255,7 +307,7 @@ class FeedForwardFn(torch.autograd.Function):
         wp2 = cache.get(("f2", x.dtype), (w2,), lambda: pack_fwd(w2, x.dtype))
         out = ops.gemm_nt(h, wp2, b2, residual=x, out_shape=x.shape)
         ctx.save_for_backward(x, w1, w2, h, pre)
-        ctx.cache = cache
+        ctx.cache, ctx.b1, ctx.b2 = cache, b1, b2
         return out
 
     @staticmethod
@@ -265,10 +317,10 @@ class FeedForwardFn(torch.autograd.Function):
         cache = ctx.cache
         wd2 = cache.get(("d2", x.dtype), (w2,), lambda: pack_dgrad(w2, x.dtype))
         dpre = ops.gemm_nt(dout, wd2, None, dact=pre, out_shape=pre.shape)          # (dout W2) * silu'(pre)
-        dw2 = ops.gemm_tn(dout, h)[0]
-        db2 = ops.colsum(dout)
-        dw1 = ops.gemm_tn(dpre, x)[0]
-        db1 = ops.colsum(dpre)
+        dw2 = conv_wgrad(dout, h, w2, "same")
+        db2 = _bias_grad(dout, ctx.b2)
+        dw1 = conv_wgrad(dpre, x, w1, "same")
+        db1 = _bias_grad(dpre, ctx.b1)
         wd1 = cache.get(("d", "same", x.dtype), (w1,), lambda: pack_dgrad(w1, x.dtype))
         dx = ops.gemm_nt(dpre, wd1, None, residual=dout, out_shape=x.shape)
         return dx, dw1, db1, dw2, db2, None
@@ -311,6 +363,7 @@ class AttentionFn(torch.autograd.Function):
         out = ops.gemm_nt(o, wpo, bo, residual=xn, out_shape=x.shape)
         ctx.save_for_backward(x, nw, mr, xn, wq, wkv, wo, qkv_r, o, lse)
         ctx.cache, ctx.geom = cache, (H, D, scale_base, scale)
+        ctx.nb, ctx.bo = nb, bo
         return out
 
     @staticmethod
@@ -322,8 +375,8 @@ class AttentionFn(torch.autograd.Function):
         dt = x.dtype
         dout = _rc(dout)
         # to_out
-        dwo = ops.gemm_tn(dout, o)[0]
-        dbo = ops.colsum(dout)
+        dwo = conv_wgrad(dout, o, wo, "same")
+        dbo = _bias_grad(dout, ctx.bo)
         wdo = cache.get(("do", dt), (wo,), lambda: pack_dgrad(wo, dt))
         do = ops.gemm_nt(dout, wdo, None, out_shape=o.shape)
         do16 = ops.cast_rows(do, torch.bfloat16)                                 # SDPA backward runs in bf16 (attention.py:101)
@@ -333,11 +386,17 @@ class AttentionFn(torch.autograd.Function):
         dqkv = ops.rope_bwd(dqkv32, dt, cos, sin, N, H + 1, H + 2, D)
         del dqkv32
         # to_q / to_kv
-        dwqkv = ops.gemm_tn(dqkv, xn)[0]
+        dwq = conv_wgrad(dqkv[..., : H * D], xn, wq, "same")
+        dwkv = conv_wgrad(dqkv[..., H * D:], xn, wkv, "same")
         wdqkv = cache.get(("dqkv", dt), (wq, wkv), lambda: torch.cat([wq.detach(), wkv.detach()], 0).t().to(dt).unsqueeze(0))
         dxn = ops.gemm_nt(dqkv, wdqkv, None, residual=dout, out_shape=x.shape)   # + residual path (x + to_out(..), x = normed)
-        dx, dnw, dnb = ops.ln_bwd(dxn, x, mr, nw)
-        return dx, dnw, dnb, dwqkv[: H * D], dwqkv[H * D:], dwo, dbo, None, None, None, None
+        tg, tb = grad_target(nw), grad_target(ctx.nb)
+        direct_norm = tg is not None and tb is not None
+        dx, dnw, dnb = ops.ln_bwd(dxn, x, mr, nw, tg if direct_norm else None, tb if direct_norm else None)
+        if direct_norm:
+            grad_done(nw); grad_done(ctx.nb)
+            dnw = dnb = None
+        return dx, dnw, dnb, dwq, dwkv, dwo, dbo, None, None, None, None
 
 
 class RowsFromNCLFn(torch.autograd.Function):

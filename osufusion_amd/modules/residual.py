@@ -85,10 +85,13 @@ class ResidualBlock(nn.Module):
         self.res_conv = nn.Conv1d(dim_in, dim_out, 1) if dim_in != dim_out else nn.Identity()
         self.se = GlobalContext(dim_out, dim_out)
         self._cm, self._cr = Fn.PackCache(), Fn.PackCache()
+        self._ss_batched: Optional[torch.Tensor] = None     # set by UNet when it evaluates all FiLM projections in one GEMM
 
     def forward_rows(self, x: torch.Tensor, t: Optional[torch.Tensor], c: Optional[torch.Tensor]) -> torch.Tensor:
         ss = None
-        if self.mlp is not None and (self.has_time_cond or self.has_cond):
+        if self._ss_batched is not None:
+            ss = self._ss_batched
+        elif self.mlp is not None and (self.has_time_cond or self.has_cond):
             emb = torch.cat([e for e in (t, c) if e is not None], dim=-1).float()
             lin = self.mlp[1]
             ss = rt.small_linear(F.silu(emb), lin.weight, lin.bias, self._cm, "mlp")     # (B, 2C): scale | shift

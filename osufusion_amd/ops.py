@@ -111,8 +111,10 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
 
 
 def gemm_tn(dy: torch.Tensor, x: torch.Tensor, *, taps: int = 1, lin: Optional[int] = None, lout: Optional[int] = None, stride: int = 1,
-            pad: int = 0, mode: int = 0, n1: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dW[t][n1][n2] = sum_m dY[m][n1] * X[rowmap(m,t)][n2] -> fp32 [taps][N1][N2]."""
+            pad: int = 0, mode: int = 0, n1: Optional[int] = None, out: Optional[torch.Tensor] = None, conv_layout: bool = False,
+            accumulate: bool = False) -> torch.Tensor:
+    """sum_m dY[m][n1] * X[rowmap(m,t)][n2] -> fp32.  Default result [taps][N1][N2]; conv_layout=True -> (N1, N2, taps), the layout
+    of a torch Conv1d weight.  `out` (dense fp32) is overwritten, or added into when accumulate=True (e.g. a parameter's .grad)."""
     M, N1, ldy = _rows(dy)
     Mx, N2, ldx = _rows(x)
     if n1 is not None:
@@ -120,12 +122,15 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, *, taps: int = 1, lin: Optional[i
     if lin is None:
         lin = lout = M
     assert dy.dtype == x.dtype and Mx // lin == M // lout
+    shape = (N1, N2, taps) if conv_layout else (taps, N1, N2)
     if out is None:
-        out = torch.zeros((taps, N1, N2), dtype=torch.float32, device=dy.device)
+        assert not accumulate
+        out = torch.empty(shape, dtype=torch.float32, device=dy.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == taps * N1 * N2
     need = _lib.load().osuf_gemm_tn_workspace_bytes(dt_of(dy), M, N1, N2, taps)
     ws = _workspace(need, dy.device) if need > 0 else None
     call("osuf_gemm_tn", dt_of(dy), _p(dy), ldy, _p(x), ldx, _p(out), N2, N1 * N2, M, N1, N2, taps, lin, lout, stride, pad, mode, 0,
-         _p(ws), need if ws is not None else 0, _stream())
+         1 if conv_layout else 0, 1 if accumulate else 0, _p(ws), need if ws is not None else 0, _stream())
     return out
 
 
@@ -143,10 +148,12 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return cur
 
 
-def colsum(y: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
+def colsum(y: torch.Tensor, n: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[n] += sum_m y[m][n]  (`out` given: accumulated into, e.g. a bias .grad; else a fresh zeroed tensor)."""
     M, N, ld = _rows(y)
     N = N if n is None else n
-    out = torch.zeros(N, dtype=torch.float32, device=y.device)
+    if out is None:
+        out = torch.zeros(N, dtype=torch.float32, device=y.device)
     call("osuf_colsum", dt_of(y), _p(y), ld, M, N, _p(out), _stream())
     return out
 
@@ -168,7 +175,9 @@ def gn_apply(y: torch.Tensor, mr: torch.Tensor, gamma: torch.Tensor, beta: torch
     return h
 
 
-def gn_bwd(dh: torch.Tensor, y: torch.Tensor, mr: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ss: Optional[torch.Tensor], L: int):
+def gn_bwd(dh: torch.Tensor, y: torch.Tensor, mr: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ss: Optional[torch.Tensor], L: int,
+           dgamma_out: Optional[torch.Tensor] = None, dbeta_out: Optional[torch.Tensor] = None):
+    """dgamma_out / dbeta_out (fp32 (C,)) are accumulated into when given (parameter .grad buffers)."""
     M, C, ldy = _rows(y)
     B = M // L
     dev = y.device
@@ -176,10 +185,12 @@ def gn_bwd(dh: torch.Tensor, y: torch.Tensor, mr: torch.Tensor, gamma: torch.Ten
     T12 = torch.zeros((B, 2, C), dtype=torch.float32, device=dev)
     S = torch.empty((B, 2), dtype=torch.float32, device=dev)
     dss = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if ss is not None else None
-    dgb = torch.zeros((2, C), dtype=torch.float32, device=dev)
+    if dgamma_out is None or dbeta_out is None:
+        dgb = torch.zeros((2, C), dtype=torch.float32, device=dev)
+        dgamma_out, dbeta_out = dgb[0], dgb[1]
     call("osuf_gn_bwd", dt_of(y), _p(dh), _rows(dh)[2], _p(y), ldy, _p(dy), C, _p(mr), _p(gamma), _p(beta), _p(ss), _p(T12), _p(S),
-         _p(dss), _p(dgb[0]), _p(dgb[1]), M, C, L, _stream())
-    return dy, dgb[0], dgb[1], dss
+         _p(dss), _p(dgamma_out), _p(dbeta_out), M, C, L, _stream())
+    return dy, dgamma_out, dbeta_out, dss
 
 
 def ln_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
@@ -190,12 +201,15 @@ def ln_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
     return out, mr
 
 
-def ln_bwd(dy: torch.Tensor, x: torch.Tensor, mr: torch.Tensor, gamma: torch.Tensor):
+def ln_bwd(dy: torch.Tensor, x: torch.Tensor, mr: torch.Tensor, gamma: torch.Tensor, dgamma_out: Optional[torch.Tensor] = None,
+           dbeta_out: Optional[torch.Tensor] = None):
     M, C, ld = _rows(x)
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
-    dgb = torch.zeros((2, C), dtype=torch.float32, device=x.device)
-    call("osuf_ln_bwd", dt_of(x), _p(dy), _rows(dy)[2], _p(x), ld, _p(dx), C, _p(mr), _p(gamma), _p(dgb[0]), _p(dgb[1]), M, C, _stream())
-    return dx, dgb[0], dgb[1]
+    if dgamma_out is None or dbeta_out is None:
+        dgb = torch.zeros((2, C), dtype=torch.float32, device=x.device)
+        dgamma_out, dbeta_out = dgb[0], dgb[1]
+    call("osuf_ln_bwd", dt_of(x), _p(dy), _rows(dy)[2], _p(x), ld, _p(dx), C, _p(mr), _p(gamma), _p(dgamma_out), _p(dbeta_out), M, C, _stream())
+    return dx, dgamma_out, dbeta_out
 
 
 def rowdot(h: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], L: int, per_sample: bool = False) -> torch.Tensor:

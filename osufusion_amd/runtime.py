@@ -92,7 +92,8 @@ def cast_rows(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return x if x.dtype == dtype else _CastFn.apply(x, dtype)
 
 
-def small_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], cache: Fn.PackCache, tag: str) -> torch.Tensor:
+def small_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], cache: Fn.PackCache, tag: str,
+                 vparams: Optional[tuple] = None) -> torch.Tensor:
     """(B, K) @ w(N, K)^T + b for the embedding-sized MLPs (time / cond / FiLM / GlobalContext), fp32 in, fp32 out.
 
     The GEMM runs in the compute dtype, as the reference does: fp32 run -> exact-f32 MFMA; bf16 autocast -> bf16 operands with
@@ -113,6 +114,6 @@ def small_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], ca
         w2 = torch.nn.functional.pad(w2, (0, 0, 0, padn))
         b = torch.nn.functional.pad(b, (0, padn)) if b is not None else None
     xr = cast_rows(x.contiguous().unsqueeze(0), dt)
-    y = Fn.ConvFn.apply(xr, w2, b.float() if b is not None else None, cache, "same", (tag, w))
+    y = Fn.ConvFn.apply(xr, w2, b.float() if b is not None else None, cache, "same", (tag, *(vparams if vparams is not None else (w,))))
     y = cast_rows(y, torch.float32).squeeze(0)
     return y[:, :N] if padn else y

@@ -79,17 +79,32 @@ class GradReducer:
         self.pending = list(self.expected)
         self.handles = []
         self.enabled = self.world > 1
+        self._index = {id(p): i for i, p in enumerate(flat.params)}
+        self._seen = set()
         if self.enabled:
             for idx, p in enumerate(flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(idx))
 
+    def param_ready(self, p) -> None:
+        """Called by the kernels' direct-accumulation path (functional.grad_done): the gradient of `p` is complete."""
+        if self.enabled:
+            idx = self._index.get(id(p))
+            if idx is not None:
+                self._ready(idx)
+
+    def _ready(self, idx: int) -> None:
+        if idx in self._seen:                              # a parameter counts once per step, however its gradient arrived
+            return
+        self._seen.add(idx)
+        b = self.bucket_of[idx]
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            s, e = self.bounds[b]
+            self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def _make_hook(self, idx: int):
         def hook(_param):
-            b = self.bucket_of[idx]
-            self.pending[b] -= 1
-            if self.pending[b] == 0:
-                s, e = self.bounds[b]
-                self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._ready(idx)
         return hook
 
     def finish(self) -> None:
@@ -104,6 +119,7 @@ class GradReducer:
             h.wait()
         self.handles = []
         self.pending = list(self.expected)
+        self._seen = set()
 
 
 class FusedAdamW:
@@ -154,6 +170,7 @@ class Trainer:
         if self.reducer.enabled:                            # identical replicas (guard; inits are already deterministic)
             dist.broadcast(self.flat.data, src=0)
         Fn.bump_weight_epoch()
+        Fn.enable_direct_grads(True, self.reducer.param_ready)
 
     def step(self, x, a, c, noise=None, timesteps=None, orig_len=None):
         from .runtime import forced_compute_dtype

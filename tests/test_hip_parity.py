@@ -404,6 +404,37 @@ def test_unet_bf16_vs_oracle_emulation(golden_dir, case):
     assert e32 < 3 * floor + 1e-2
 
 
+def test_direct_grad_accumulation_matches_autograd(golden_dir):
+    """Trainer path (kernels add straight into the flat .grad buffer, autograd sees None) == plain autograd gradients.
+    fp32 compute so that only summation order differs; errors are measured against each tensor's own scale plus a floor at
+    1e-4 of the largest gradient (se.to_k.bias gradients are mathematically zero: softmax is shift-invariant)."""
+    from osufusion_amd.train import Trainer
+    meta, cfgd, model = _build_model("unet_tiny", golden_dir)
+    x, a, c, t, noise = (T(v) for v in synth_inputs("unet_tiny", meta["B"], meta["L"]))
+    with oa.forced_compute_dtype(torch.float32):
+        model.loss_with(x, a, c, noise, t, cond_drop_prob=0.0).backward()
+    ref = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    gmax = max(v.abs().max().item() for v in ref.values())
+    try:
+        trainer = Trainer(model, compute_dtype=torch.float32)           # re-homes params/grads, enables the direct path
+        trainer.flat.zero_grad()
+        with oa.forced_compute_dtype(torch.float32):
+            model.loss_with(x, a, c, noise, t, cond_drop_prob=0.0).backward()
+        torch.cuda.synchronize()
+        worst, worst_k = 0.0, ""
+        for k, p in model.named_parameters():
+            assert trainer.flat.grad.data_ptr() <= p.grad.data_ptr() < trainer.flat.grad.data_ptr() + 4 * trainer.flat.numel
+            e = ((p.grad - ref[k]).abs().max() / (ref[k].abs().max() + 1e-4 * gmax)).item()
+            if e > worst:
+                worst, worst_k = e, k
+        report("direct_grad_vs_autograd", max_rel=worst)
+        assert worst < 5e-3, worst_k
+        loss, gn = trainer.step(x, a, c, noise, t)                       # and one fused optimizer step on the flat buffers
+        assert torch.isfinite(loss).item() and torch.isfinite(gn).item()
+    finally:
+        Fn.enable_direct_grads(False)
+
+
 def test_sampler_vs_oracle(golden_dir):
     meta, cfgd, model = _build_model("unet_tiny", golden_dir)
     cfg = O.UNetConfig(**cfgd)

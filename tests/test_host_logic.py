@@ -59,7 +59,7 @@ def emu_gemm_nt(a, w, bias=None, *, taps=1, n_out=None, lin=None, lout=None, str
     return C.reshape(out_shape) if out_shape is not None else C
 
 
-def emu_gemm_tn(dy, x, *, taps=1, lin=None, lout=None, stride=1, pad=0, mode=0, n1=None, out=None):
+def emu_gemm_tn(dy, x, *, taps=1, lin=None, lout=None, stride=1, pad=0, mode=0, n1=None, out=None, conv_layout=False, accumulate=False):
     Y = dy.reshape(-1, dy.shape[-1]).double()
     X = x.reshape(-1, x.shape[-1]).double()
     if lin is None:
@@ -72,7 +72,12 @@ def emu_gemm_tn(dy, x, *, taps=1, lin=None, lout=None, stride=1, pad=0, mode=0, 
             s = map_row(i, t, lin, lout, stride, pad, mode)
             if s >= 0:
                 G[t] += torch.outer(Y[m], X[b * lin + s])
-    return G.float()
+    G = G.float()
+    res = G.permute(1, 2, 0).contiguous() if conv_layout else G
+    if out is not None:
+        out.copy_(out + res.reshape(out.shape) if accumulate else res.reshape(out.shape))
+        return out
+    return res
 
 
 @pytest.fixture()
