@@ -101,10 +101,17 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+    # rehearsal knobs (CPU-side testing of the N>1 path on a 1-GPU box): OSUF_DIST_BACKEND=gloo, OSUF_SINGLE_DEVICE=1
+    backend = os.environ.get("OSUF_DIST_BACKEND", "nccl")
+    if os.environ.get("OSUF_SINGLE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
 
     from osufusion_amd import ops
     from osufusion_amd.train import Trainer
@@ -114,6 +121,7 @@ def main() -> None:
     x, a, c, noise, t = synth_batch(rank, device, args.batch, args.length)
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
