@@ -909,16 +909,36 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, floa
     // a thread owns 4 consecutive i: float4 loads of the partials (16 B/lane), then 4*taps contiguous outputs
     const long n = n12 * taps, q12 = n12 >> 2;            // n12 % 4 == 0 is guaranteed by the launcher
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < q12; q += (long)gridDim.x * blockDim.x) {
-      for (int t = 0; t < taps; ++t) {
-        f32x4 a = reinterpret_cast<const f32x4*>(ws + (long)t * n12)[q];
-        for (int sidx = 1; sidx < splits; ++sidx) {
-          f32x4 b = reinterpret_cast<const f32x4*>(ws + (long)sidx * n + (long)t * n12)[q];
-          a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
-        }
+      if (taps == 3) {                                     // k3 convs (all but the stems): 12 outputs = three 16-B stores
+        f32x4 a[3];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float* dst = dW + (4 * q + e) * taps + t;
-          *dst = accumulate ? *dst + a[e] : a[e];
+        for (int t = 0; t < 3; ++t) {
+          a[t] = reinterpret_cast<const f32x4*>(ws + (long)t * n12)[q];
+          for (int sidx = 1; sidx < splits; ++sidx) {
+            f32x4 b = reinterpret_cast<const f32x4*>(ws + (long)sidx * n + (long)t * n12)[q];
+            a[t][0] += b[0]; a[t][1] += b[1]; a[t][2] += b[2]; a[t][3] += b[3];
+          }
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(dW + 12 * q);
+        f32x4 o0 = {a[0][0], a[1][0], a[2][0], a[0][1]}, o1 = {a[1][1], a[2][1], a[0][2], a[1][2]}, o2 = {a[2][2], a[0][3], a[1][3], a[2][3]};
+        if (accumulate) {
+          f32x4 d0 = dst[0], d1 = dst[1], d2 = dst[2];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o0[e] += d0[e]; o1[e] += d1[e]; o2[e] += d2[e]; }
+        }
+        dst[0] = o0; dst[1] = o1; dst[2] = o2;
+      } else {
+        for (int t = 0; t < taps; ++t) {
+          f32x4 a = reinterpret_cast<const f32x4*>(ws + (long)t * n12)[q];
+          for (int sidx = 1; sidx < splits; ++sidx) {
+            f32x4 b = reinterpret_cast<const f32x4*>(ws + (long)sidx * n + (long)t * n12)[q];
+            a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float* dst = dW + (4 * q + e) * taps + t;
+            *dst = accumulate ? *dst + a[e] : a[e];
+          }
         }
       }
     }
