@@ -29,6 +29,11 @@ import torch.distributed as dist  # noqa: E402
 MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 DIM_H, BATCH, LENGTH, HEADS, HEAD_DIM = 256, 32, 4096, 16, 64
 STEP_TFLOP = 125.1                      # 3 x 1,303 GFLOP/sample x 32 (recompute not counted)
+# HBM-side bytes per launch of each attention kernel, mean over the 39 launches of one step at the headline shape, from separate
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command (profiles/r01_pmc/bench_{fetch,write}_size_by_kernel.csv);
+# FETCH_SIZE doubled as MI355X_MICROARCH.md "HBM" prescribes for 16-B/lane streams on gfx950.  bench.py cannot run the profiler
+# on itself, so the offline measurement is quoted (algorithmic bytes of the dK/dV kernel over the same mix: 289 MB).
+PMC_TRAFFIC_BYTES = {"osuf_mqa_bwd_dkv": 2 * 129.9e6 + 29.7e6, "osuf_mqa_bwd_dq": 2 * 182.0e6 + 237.5e6, "osuf_mqa_fwd": 2 * 133.4e6 + 219.0e6}
 
 
 def synth_batch(rank: int, device, batch: int, length: int):
@@ -159,7 +164,8 @@ def main() -> None:
             tf = sum(per * args.batch * HEADS * n * n * HEAD_DIM for n in stats[dom]["sizes"]) / 1e12
             ach = tf / (stats[dom]["total_ms"] / 1e3)
             roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None, launches=stats[dom]["launches"],
+                        frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4), traffic=PMC_TRAFFIC_BYTES.get(dom) if full else None,
+                        traffic_unit="HBM-side bytes per launch (offline rocprofv3 PMC, profiles/r01_pmc/)", launches=stats[dom]["launches"],
                         mean_launch_ms=round(stats[dom]["total_ms"] / stats[dom]["launches"], 3),
                         step_frac_of_peak=round(STEP_TFLOP / (ms / 1e3) / MFMA_BF16_PEAK_TFLOPS, 4) if full else None,
                         all_kernels_ms_per_step={k: round(v["total_ms"] / args.steps, 2) for k, v in stats.items()})
