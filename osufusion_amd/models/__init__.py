@@ -1,1 +1,1 @@
-from . import diffusion  # noqa: F401
+from . import diffusion, rectified_flow  # noqa: F401

@@ -435,6 +435,40 @@ def test_direct_grad_accumulation_matches_autograd(golden_dir):
         Fn.enable_direct_grads(False)
 
 
+def test_rectified_flow_vs_oracle(golden_dir):
+    """Rectified-flow wrapper (rectified_flow.py:57-111): training loss + gradients and the 2*(S-1)-evaluation midpoint sampler."""
+    from oracle import rectified_flow_oracle as RO
+    from osufusion_amd.models.rectified_flow import OsuFusion as RFOsuFusion
+    meta = json.loads((golden_dir / "unet_cases.json").read_text())["unet_tiny"]
+    cfgd = {k: (tuple(v) if isinstance(v, list) else v) for k, v in meta["cfg"].items()}
+    kw = {k: v for k, v in cfgd.items() if not k.startswith("dim_in_")}
+    model = RFOsuFusion(kw.pop("dim_h"), **kw).to(DEV)
+    load_pattern(model.unet)
+    assert model.sample_timesteps == 16 and model.cond_drop_prob == 0.5
+    cfg = O.UNetConfig(**cfgd)
+    p = {"unet." + k: v.requires_grad_() for k, v in O.make_params(cfg).items()}
+    x, a, c, t, noise = (torch.from_numpy(v) for v in synth_inputs("rf", 2, 256))
+    times = torch.tensor([0.3, 0.85])
+    ref = RO.training_loss(p, cfg, x, a, c, noise, times, cond_drop_prob=0.0)
+    ref.backward()
+    with oa.forced_compute_dtype(torch.float32):
+        got = model.loss_with(x.to(DEV), a.to(DEV), c.to(DEV), noise.to(DEV), times.to(DEV), cond_drop_prob=0.0)
+        got.backward()
+    assert abs(got.item() - ref.item()) < 1e-3 * abs(ref.item())
+    gref = torch.stack([p["unet." + k].grad.norm() for k, _ in model.unet.named_parameters()])
+    ggot = torch.stack([v.grad.norm().cpu() for _, v in model.unet.named_parameters()])
+    assert ((ggot - gref).abs() / (gref + 1e-3 * gref.max())).max() < 2e-2
+    model.sample_timesteps = 4
+    with torch.no_grad():
+        for cs in (1.0, 2.0):
+            want = RO.sample({k: v.detach() for k, v in p.items()}, cfg, a, c, noise.clone(), sampling_steps=4, cond_scale=cs)
+            with oa.forced_compute_dtype(torch.float32):
+                have = model.sample(a.to(DEV), c.to(DEV), noise.to(DEV), cond_scale=cs)
+            e = rell2(have, want)
+            report(f"rf_midpoint_3step/cond_scale_{cs}", rel_l2=e)
+            assert e < 1e-2, cs
+
+
 def test_sampler_vs_oracle(golden_dir):
     meta, cfgd, model = _build_model("unet_tiny", golden_dir)
     cfg = O.UNetConfig(**cfgd)

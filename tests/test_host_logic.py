@@ -202,6 +202,23 @@ def test_api_surface_mirrors_reference():
         m(torch.zeros(1, 6, 32), torch.zeros(1, 96, 16), torch.zeros(1, 5))
 
 
+def test_rectified_flow_api_and_oracle_selfcheck():
+    """API mirror of models/rectified_flow.py + the oracle's midpoint rule on a linear ODE (dy/dt = -y: one exact check of the
+    restated torchdiffeq fixed-grid midpoint step: y1 = y0 * (1 - dt + dt^2 / 2))."""
+    import inspect
+    from oracle import rectified_flow_oracle as RO
+    from osufusion_amd.models.rectified_flow import OsuFusion as RF, cosmap
+    assert list(inspect.signature(RF.sample).parameters)[1:] == ["a", "c", "x", "cond_scale"]
+    assert inspect.signature(RF.sample).parameters["cond_scale"].default == 2.0
+    assert inspect.signature(RF.__init__).parameters["sampling_timesteps"].default == 16
+    t = torch.tensor([0.0, 0.5, 1.0])
+    assert torch.allclose(cosmap(t)[:2], torch.tensor([0.0, 0.5]), atol=1e-6) and abs(cosmap(t)[2].item() - 1.0) < 1e-6
+    assert torch.allclose(RO.cosmap(t), cosmap(t))
+    with pytest.raises(AssertionError):
+        RF(32, dim_h_mult=(1, 2), num_layer_blocks=(1, 1), num_middle_transformers=1, cross_embed_kernel_sizes=(3,), attn_heads=2)(
+            torch.zeros(1, 6, 32), torch.zeros(1, 96, 16), torch.zeros(1, 5))
+
+
 def test_product_path_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("CPU-only check")
