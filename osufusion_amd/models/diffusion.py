@@ -89,6 +89,7 @@ class OsuFusion(nn.Module):
         self.sampling_timesteps = sampling_timesteps
         self.cond_drop_prob = cond_drop_prob
         self._full_bf16 = False
+        self.use_hip_graph = False       # capture one DDIM step (2B-batched CFG forward + fused step kernel) in a hipGraph
 
     def set_full_bf16(self) -> None:
         """diffusion.py:56-57 casts the UNet weights to bf16; here the fp32 masters are kept and every kernel computes in
@@ -122,13 +123,35 @@ class OsuFusion(nn.Module):
                 ce = unet.embed_cond(torch.cat([c, c], 0), torch.cat([keep, ~keep], 0))
             else:
                 ce = unet.embed_cond(c, keep)
-            for t in self.scheduler.timesteps.tolist():
-                xin = torch.cat([x, x], 0) if cfg else x
-                t_batched = torch.full((xin.shape[0],), t, dtype=torch.int64, device=device)
+            steps = self.scheduler.timesteps.tolist()
+            nb = 2 * b if cfg else b
+            coef_table = torch.tensor([[self.scheduler.step_coefficients(t)] * b for t in steps], dtype=torch.float32, device=device)
+            t_table = torch.tensor([[t] * nb for t in steps], dtype=torch.int64, device=device)
+            x_buf, t_buf, coef_buf = x.clone(), t_table[0].clone(), coef_table[0].clone()
+
+            def one_step() -> None:                      # reads x_buf / t_buf / coef_buf, writes x_buf (static buffers)
+                xin = torch.cat([x_buf, x_buf], 0) if cfg else x_buf
                 x_rows = unet.init_x.forward_rows(F.pad(xin, (0, pad_len), value=-1.0), dtype)
-                pred = unet.denoise_rows(x_rows, a_rows, unet.embed_time(t_batched), ce)[:, :, :n].contiguous()
-                coef = torch.tensor([self.scheduler.step_coefficients(t)] * b, dtype=torch.float32, device=device)
-                x = ops.ddim_step(x, pred[:b], pred[b:] if cfg else None, cond_scale, coef)
+                pred = unet.denoise_rows(x_rows, a_rows, unet.embed_time(t_buf), ce)[:, :, :n].contiguous()
+                x_buf.copy_(ops.ddim_step(x_buf, pred[:b], pred[b:] if cfg else None, cond_scale, coef_buf))
+
+            graph = None
+            for i in range(len(steps)):
+                if i > 0:
+                    t_buf.copy_(t_table[i])
+                    coef_buf.copy_(coef_table[i])
+                if graph is not None:
+                    graph.replay()
+                    continue
+                one_step()                               # eager (also warms pack caches / RoPE tables before a capture)
+                if self.use_hip_graph and i == 0 and len(steps) > 1:
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    keep_x = x_buf.clone()
+                    with torch.cuda.graph(graph):        # capture records the launches only; x_buf is restored below
+                        one_step()
+                    x_buf.copy_(keep_x)
+            x = x_buf
         return x
 
     def forward(self, x: torch.Tensor, a: torch.Tensor, c: torch.Tensor, orig_len: Optional[torch.Tensor] = None) -> torch.Tensor:
