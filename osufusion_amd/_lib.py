@@ -11,7 +11,8 @@ from ctypes import c_double, c_float, c_int, c_long, c_void_p
 from pathlib import Path
 
 _CSRC = Path(__file__).resolve().parent / "csrc"
-LIB_PATH = _CSRC / "libosuf_hip.so"
+# OSUF_HIP_LIB: load another build of the same C ABI (same-box A/B timing of two kernel revisions; tools/ab.sh)
+LIB_PATH = Path(os.environ["OSUF_HIP_LIB"]).resolve() if os.environ.get("OSUF_HIP_LIB") else _CSRC / "libosuf_hip.so"
 
 P, L, I, F = c_void_p, c_long, c_int, c_float
 

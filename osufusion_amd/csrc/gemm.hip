@@ -377,97 +377,9 @@ static constexpr int kBig = 256;
 static constexpr int kBigStage = 2 * kBig * 128;        // 64 KiB: A 256 rows + B 256 rows, 128 B of K each
 
 template <typename T>
-__global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BK = Mma<T>::BK;
-  constexpr int EPC = ElemTraits<T>::kPer16B;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 2, wc = wave & 3;
-  const int tiles_n = (g.N + kBig - 1) / kBig;
-  // XCD-aware tile order (speed only): block ids are dealt round-robin to the 8 XCDs, so the N-tiles that share one
-  // M-tile's A rows get ids 8 apart -> same XCD (same L2), dispatched back to back.
-  const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;
-  const int mt = (qid / tiles_n) * 8 + xcd;
-  const int m0 = mt * kBig, n0 = (qid % tiles_n) * kBig;
-  if (m0 >= g.M) return;
-  const T* A = reinterpret_cast<const T*>(g.A);
-  const T* W = reinterpret_cast<const T*>(g.W);
-  const char* zero = reinterpret_cast<const char*>(g_zero_page);
-
-  int a_base[4], a_pos[4], chunk[4];
-  bool b_ok[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 8 + (lane >> 3);
-    chunk[i] = (lane & 7) ^ ((row >> 1) & 7);
-    const int m = m0 + row;
-    if (m < g.M) { int b = m / g.rm.Lout; a_base[i] = b * g.rm.Lin; a_pos[i] = m - b * g.rm.Lout; }
-    else { a_base[i] = 0; a_pos[i] = -1; }
-    b_ok[i] = (n0 + row) < g.N;
-  }
-  const int ksteps = (g.K + BK - 1) / BK;
-  const int nsteps = g.taps * ksteps;
-
-  auto issue = [&](int step, int buf) {
-    const int t = step / ksteps, kb = step - t * ksteps;
-    char* sa = smem + buf * kBigStage + wave * 4096;
-    char* sb = sa + kBig * 128;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = kb * BK + chunk[i] * EPC;
-      const bool kok = k < g.K;
-      const char* pa = zero;
-      const char* pb = zero;
-      if (kok && a_pos[i] >= 0) {
-        int s = map_row(g.rm, a_pos[i], t);
-        if (s >= 0) pa = reinterpret_cast<const char*>(A + (long)(a_base[i] + s) * g.lda + k);
-      }
-      if (kok && b_ok[i]) pb = reinterpret_cast<const char*>(W + (long)t * g.tapstride + (long)(n0 + (wave * 4 + i) * 8 + (lane >> 3)) * g.ldw + k);
-      __builtin_amdgcn_global_load_lds((gas_ptr)pa, (las_ptr)(sa + i * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gas_ptr)pb, (las_ptr)(sb + i * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
+__device__ __forceinline__ void gemm_big_epilogue(const GemmArgs& g, f32x16 (&acc)[4][2], char* smem, int m0, int n0, int tid, int lane, int wave,
+                                                  int wr, int wc) {
   const int lr = lane & 31, lh = lane >> 5;
-  issue(0, 0);
-  __syncthreads();
-  for (int step = 0; step < nsteps; ++step) {
-    const int buf = step & 1;
-    if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
-    const char* sa = smem + buf * kBigStage;
-    const char* sb = sa + kBig * 128;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      u32x4 fa[4], fb[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(sa + swz_off(wr * 128 + i * 32 + lr, 2 * ks + lh));
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const u32x4*>(sb + swz_off(wc * 64 + j * 32 + lr, 2 * ks + lh));
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if constexpr (sizeof(T) == 2) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
-                                                                 __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
-          } else {
-            f32x4 va = __builtin_bit_cast(f32x4, fa[i]), vb = __builtin_bit_cast(f32x4, fb[j]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e], vb[e], acc[i][j], 0, 0, 0);
-          }
-        }
-    }
-    __syncthreads();
-  }
-
   // ---- epilogue: per wave, two passes of a 64x64 fp32 sub-tile through its private 16 KiB LDS slice --------
   float* cs = reinterpret_cast<float*>(smem + wave * 16384);
   float* sstat = reinterpret_cast<float*>(smem + 2 * kBigStage);
@@ -563,6 +475,156 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(GemmArgs g) {
       if (v != 0.f && b * g.rm.Lout < g.M) atomic_add_f64(g.stats + 2 * b + (tid & 1), (double)v);
     }
   }
+}
+
+// DBG (bottleneck triage builds, selected by OSUF_GEMM_DBG; results are garbage unless 0): 1 = no MFMA, 2 = no LDS fragment
+// reads, 3 = no global->LDS DMA, 4 = DMA only, 5 = DMA only from one hot 1-KiB region (memory-side vs LDS-side cost).
+template <typename T, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BK = Mma<T>::BK;
+  constexpr int EPC = ElemTraits<T>::kPer16B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (g.N + kBig - 1) / kBig;
+  // XCD-aware tile order (speed only): block ids are dealt round-robin to the 8 XCDs, so the N-tiles that share one
+  // M-tile's A rows get ids 8 apart -> same XCD (same L2), dispatched back to back.
+  const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;
+  const int mt = (qid / tiles_n) * 8 + xcd;
+  const int m0 = mt * kBig, n0 = (qid % tiles_n) * kBig;
+  if (m0 >= g.M) return;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  // Per-lane DMA sources.  The row maps (taps, reflect / nearest-x2 / dgrad geometries) are evaluated once per TAP; inside a
+  // tap every K-step is `pointer += 128 B`.  (Round-1 triage: re-deriving the addresses every K-step cost more issue slots
+  // than the 32 MFMAs of the step -- removing it took the K=2048 linear from 726 to the number in DESIGN.md.)
+  int a_base[4], a_pos[4], koff[4];
+  bool b_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    koff[i] = ((lane & 7) ^ ((row >> 1) & 7)) * EPC;
+    const int m = m0 + row;
+    if (m < g.M) { int b = m / g.rm.Lout; a_base[i] = b * g.rm.Lin; a_pos[i] = m - b * g.rm.Lout; }
+    else { a_base[i] = 0; a_pos[i] = -1; }
+    b_ok[i] = (n0 + row) < g.N;
+  }
+  const int ksteps = (g.K + BK - 1) / BK;
+  const int nsteps = g.taps * ksteps;
+  const bool ktail = (g.K % BK) != 0;                      // only then can a 16-B chunk of the last K-step lie beyond K
+
+  const char* pa[4];
+  const char* pb[4];
+  int ia[4], ib[4];
+  auto set_tap = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pa[i] = zero; ia[i] = 0;
+      if (a_pos[i] >= 0) {
+        int s = map_row(g.rm, a_pos[i], t);
+        if (s >= 0) { pa[i] = reinterpret_cast<const char*>(A + (long)(a_base[i] + s) * g.lda + koff[i]); ia[i] = BK * (int)sizeof(T); }
+      }
+      pb[i] = zero; ib[i] = 0;
+      if (b_ok[i]) {
+        pb[i] = reinterpret_cast<const char*>(W + (long)t * g.tapstride + (long)(n0 + (wave * 4 + i) * 8 + (lane >> 3)) * g.ldw + koff[i]);
+        ib[i] = BK * (int)sizeof(T);
+      }
+    }
+  };
+  int itap = 0, ikb = 0;                                   // (tap, K-step) of the NEXT stage to be issued
+  set_tap(0);
+  // One quarter (one A + one B DMA instruction per wave) of the next stage; the four quarters are spread over the four
+  // k16 sub-steps of the current stage so the memory pipe accepts them while the MFMAs run (issuing all eight up front
+  // stalled every wave of the barrier-synchronised workgroup on the address queue with the matrix cores idle).
+  auto issue_part = [&](int buf, int i) {
+    char* sa = smem + buf * kBigStage + wave * 4096;
+    char* sb = sa + kBig * 128;
+    const char* qa = pa[i];
+    const char* qb = pb[i];
+    if (ktail && ikb == ksteps - 1 && ikb * BK + koff[i] >= g.K) { qa = zero; qb = zero; }
+    if (DBG == 5) { qa = reinterpret_cast<const char*>(A) + lane * 16; qb = reinterpret_cast<const char*>(W) + lane * 16; }
+    __builtin_amdgcn_global_load_lds((gas_ptr)qa, (las_ptr)(sa + i * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gas_ptr)qb, (las_ptr)(sb + i * 1024), 16, 0, 0);
+    pa[i] += ia[i];
+    pb[i] += ib[i];
+  };
+  auto issue_done = [&]() {
+    if (++ikb == ksteps) {
+      ikb = 0;
+      if (++itap < g.taps) set_tap(itap);
+    }
+  };
+  auto issue = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_part(buf, i);
+    issue_done();
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  if (DBG != 3) issue(0);
+  __syncthreads();
+  u32x4 dfa[4], dfb[2];
+  if (DBG == 2) {
+    for (int i = 0; i < 4; ++i) dfa[i] = u32x4{(uint32_t)lane, 1u, 2u, 3u};
+    for (int j = 0; j < 2; ++j) dfb[j] = u32x4{(uint32_t)lane, 5u, 6u, 7u};
+  }
+  for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
+    const bool more = DBG != 3 && step + 1 < nsteps;
+    const char* sa = smem + buf * kBigStage;
+    const char* sb = sa + kBig * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 fa[4], fb[2];
+      if (more) issue_part(buf ^ 1, ks);
+      if (DBG >= 4) continue;
+      if (DBG == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(dfa[i])); fa[i] = dfa[i]; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { asm volatile("" : "+v"(dfb[j])); fb[j] = dfb[j]; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(sa + swz_off(wr * 128 + i * 32 + lr, 2 * ks + lh));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const u32x4*>(sb + swz_off(wc * 64 + j * 32 + lr, 2 * ks + lh));
+      }
+      if (DBG == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(fb[j]));
+        continue;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (sizeof(T) == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                 __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+          } else {
+            f32x4 va = __builtin_bit_cast(f32x4, fa[i]), vb = __builtin_bit_cast(f32x4, fb[j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e], vb[e], acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    if (more) issue_done();
+    __syncthreads();
+  }
+
+  gemm_big_epilogue<T>(g, acc, smem, m0, n0, tid, lane, wave, wr, wc);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -764,24 +826,38 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(WgradArgs g) {
     srow[i] = (wave * 4 + i) * 2 + (lane >> 5);
     scol[i] = ((lane & 31) ^ ((srow[i] & 3) << 2)) * 8;        // logical column (elements) stored at this LDS position
   }
+  // Per-lane DMA sources, advanced incrementally: 64 rows of m per step.  (sample, position) of each lane's row are carried
+  // instead of re-divided every step, and the dY pointer is a plain `+= 64 rows` (same triage finding as gemm_nt_big_kernel).
+  int sb_[4], sp_[4];
+  const char* py[4];
+  bool y_ok[4], x_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m_begin + srow[i];
+    sb_[i] = m / g.rm.Lout;
+    sp_[i] = m - sb_[i] * g.rm.Lout;
+    y_ok[i] = n1_0 + scol[i] < g.N1;
+    x_ok[i] = n2_0 + scol[i] < g.N2;
+    py[i] = reinterpret_cast<const char*>(dY + (long)m * g.ldy + n1_0 + scol[i]);
+  }
+  const long ystep = (long)BKM * g.ldy * (long)sizeof(bf16_t);
   auto issue = [&](int mb, int buf) {
     char* sy = smem + buf * 2 * TILEB + wave * 4096;
     char* sx = sy + TILEB;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = mb + srow[i];
-      const char* py = zero;
-      const char* px = zero;
-      if (m < m_end) {
-        if (n1_0 + scol[i] < g.N1) py = reinterpret_cast<const char*>(dY + (long)m * g.ldy + n1_0 + scol[i]);
-        if (n2_0 + scol[i] < g.N2) {
-          const int b = m / g.rm.Lout;
-          const int s2 = map_row(g.rm, m - b * g.rm.Lout, t);
-          if (s2 >= 0) px = reinterpret_cast<const char*>(X + (long)(b * g.rm.Lin + s2) * g.ldx + n2_0 + scol[i]);
-        }
+      const bool in = mb + srow[i] < m_end;
+      const char* qy = (in && y_ok[i]) ? py[i] : zero;
+      const char* qx = zero;
+      if (in && x_ok[i]) {
+        const int s2 = map_row(g.rm, sp_[i], t);
+        if (s2 >= 0) qx = reinterpret_cast<const char*>(X + (long)(sb_[i] * g.rm.Lin + s2) * g.ldx + n2_0 + scol[i]);
       }
-      __builtin_amdgcn_global_load_lds((gas_ptr)py, (las_ptr)(sy + i * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gas_ptr)px, (las_ptr)(sx + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gas_ptr)qy, (las_ptr)(sy + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gas_ptr)qx, (las_ptr)(sx + i * 1024), 16, 0, 0);
+      py[i] += ystep;
+      sp_[i] += BKM;
+      while (sp_[i] >= g.rm.Lout) { sp_[i] -= g.rm.Lout; ++sb_[i]; }
     }
   };
 
@@ -1018,9 +1094,24 @@ extern "C" int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, l
   if (use_big) {
     const int lds_big = 2 * kBigStage + 1024;
     static bool big_attr = false;
-    if (!big_attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big); big_attr = true; }
+    if (!big_attr) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<bf16_t, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<bf16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<bf16_t, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
+      big_attr = true;
+    }
     const long tm = (M + kBig - 1) / kBig, tn = (N + kBig - 1) / kBig;
-    hipLaunchKernelGGL(gemm_nt_big_kernel<bf16_t>, dim3((int)(((tm + 7) / 8) * 8 * tn)), dim3(512), lds_big, stream, g);
+    static const int dbg = getenv("OSUF_GEMM_DBG") ? atoi(getenv("OSUF_GEMM_DBG")) : 0;
+    const dim3 grid_big((int)(((tm + 7) / 8) * 8 * tn));
+    if (dbg == 1) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 1>), grid_big, dim3(512), lds_big, stream, g);
+    else if (dbg == 2) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 2>), grid_big, dim3(512), lds_big, stream, g);
+    else if (dbg == 3) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 3>), grid_big, dim3(512), lds_big, stream, g);
+    else if (dbg == 4) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 4>), grid_big, dim3(512), lds_big, stream, g);
+    else if (dbg == 5) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 5>), grid_big, dim3(512), lds_big, stream, g);
+    else hipLaunchKernelGGL(gemm_nt_big_kernel<bf16_t>, grid_big, dim3(512), lds_big, stream, g);
   } else if (regstage) {
     if (dtype == OSUF_DT_BF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16_t>, dim3(grid), dim3(256), lds, stream, g);
     else hipLaunchKernelGGL(gemm_nt_kernel<float>, dim3(grid), dim3(256), lds, stream, g);

@@ -1,0 +1,21 @@
+import sys
+sys.path.insert(0, "/root/repo")
+import torch
+from osufusion_amd import ops
+def timeit(fn, iters=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+M = 131072
+for N, K in ((1024, 2048), (1024, 1024), (1024, 512), (1152, 256), (256, 256)):
+    for padk in (0, 64, 32, 8):
+        for padn in (0, 64):
+            xs = torch.randn(M, K + padk, device="cuda").bfloat16(); x = xs[:, :K]
+            w = (torch.randn(1, N, K, device="cuda") * 0.05).bfloat16()
+            outs = torch.empty(M, N + padn, device="cuda", dtype=torch.bfloat16); out = outs[:, :N]
+            t = timeit(lambda: ops.gemm_nt(x, w, None, out=out))
+            print(f"N={N} K={K} lda=K+{padk} ldc=N+{padn}: {t*1e3:8.1f} us  {2.0*M*N*K/t/1e9:7.0f} TF/s", flush=True)

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Build the kernels of a git revision (default HEAD) into osufusion_amd/csrc/libosuf_hip_base.so for same-box A/B timing:
+#   tools/build_base.sh [rev];  then on the GPU box:  OSUF_HIP_LIB=osufusion_amd/csrc/libosuf_hip_base.so python bench.py ...
+set -e
+cd /root/repo
+REV=${1:-HEAD}
+D=$(mktemp -d /tmp/osuf_base.XXXX)
+for f in common.hpp gemm.hip norm.hip attn.hip elementwise.hip; do git show "$REV:osufusion_amd/csrc/$f" > "$D/$f"; done
+for f in gemm norm attn elementwise; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$D/$f.hip" -o "$D/$f.o" &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o osufusion_amd/csrc/libosuf_hip_base.so "$D"/*.o
+rm -rf "$D"
+ls -la osufusion_amd/csrc/libosuf_hip_base.so
