@@ -124,6 +124,14 @@ int osuf_adamw(float* p, const float* g, float* m, float* v, long n, float lr, f
                int step, const float* gscale, hipStream_t stream);
 int osuf_clip_coef(const double* sumsq, float max_norm, float base, float* coef, float* total_norm, hipStream_t stream);
 int osuf_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t stream);
+/* GEMM operand layouts of one conv / linear weight, both from the fp32 master (O, I, k) in one pass -- what the reference gets
+ * for free from cuDNN's filter transforms inside F.conv1d / its backward (modules/unet.py:61-101, residual.py:75-137):
+ *   F[t][o][i] = w[o][i][t]                                (forward operand, [taps][N=O][K=I]; may be NULL)
+ *   D[t'][i][o]: dkind 0 flipped taps (same conv), 1 Downsample dgrad (4 taps, tap 3 = reflected column), 2 Upsample dgrad
+ *                (4 taps [w2, w1+w2, w0+w1, w0]); dkind 1/2 need k == 3.  (may be NULL)
+ * out_dtype OSUF_DT_*; f_ld / d_ld = row strides and *_tapstride = tap strides of the destinations, in elements. */
+int osuf_pack_weight(const float* w, int O, int I, int k, int out_dtype, void* F, long f_ld, long f_tapstride, void* D, long d_ld,
+                     long d_tapstride, int dkind, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,7 @@ SIGNATURES = {
     "osuf_adamw": [P, P, P, P, L, F, F, F, F, F, I, P, P],
     "osuf_clip_coef": [P, F, F, P, P, P],
     "osuf_cast_f32_bf16": [P, P, L, P],
+    "osuf_pack_weight": [P, I, I, I, I, P, L, L, P, L, L, I, P],
 }
 
 _lib = None

@@ -35,6 +35,31 @@ class PackCache:
         self._d[key] = (ver, t)
         return t
 
+    def packs(self, key: Tuple, params: Tuple[torch.Tensor, ...], weights, kind: str, dt: torch.dtype):
+        """(fwd [k][O][I], dgrad [k'][I][O]) operands of a weight -- or of several weights stacked along O (the fused q|kv
+        projection) -- built from the fp32 masters by one osuf_pack_weight launch per weight and cached like get()."""
+        ver = (_WEIGHT_EPOCH, *[(p._version, p.data_ptr()) for p in params])
+        hit = self._d.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        ws = weights if isinstance(weights, (tuple, list)) else (weights,)
+        with torch.no_grad():
+            ws = [w.detach().float().contiguous() for w in ws]
+            if len(ws) == 1:
+                pair = ops.pack_weight(ws[0], dt, kind)
+            else:
+                I = ws[0].shape[1]
+                total = sum(w.shape[0] for w in ws)
+                fwd = torch.empty((1, total, I), dtype=dt, device=ws[0].device)
+                dgr = torch.empty((1, I, total), dtype=dt, device=ws[0].device)
+                off = 0
+                for w in ws:
+                    ops.pack_weight(w, dt, kind, fwd=fwd, dgrad=dgr, row_offset=off)
+                    off += w.shape[0]
+                pair = (fwd, dgr)
+        self._d[key] = (ver, pair)
+        return pair
+
 
 # ---- direct gradient accumulation ---------------------------------------------------------------------------
 # With a Trainer, every parameter owns a persistent fp32 .grad view into one flat buffer.  The backward kernels then add
@@ -83,28 +108,6 @@ def _rc(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-# pack builders -------------------------------------------------------------------------------------------
-def pack_fwd(w: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
-    """(Cout, Cin, k) -> [k][Cout][Cin];  (out, in) -> [1][out][in]."""
-    if w.dim() == 2:
-        return w.detach().to(dt).unsqueeze(0)
-    return w.detach().permute(2, 0, 1).to(dt)
-
-
-def pack_dgrad(w: torch.Tensor, dt: torch.dtype, kind: str = "same") -> torch.Tensor:
-    """Weights of the input-gradient conv, [taps'][Cin][Cout] (see gemm.hip row-map modes)."""
-    if w.dim() == 2:
-        return w.detach().t().to(dt).unsqueeze(0)
-    wt = w.detach().permute(2, 1, 0)                       # [k][Cin][Cout]
-    if kind == "same":
-        return wt.flip(0).to(dt)
-    if kind == "down":                                     # mode 3: taps 0..2 as is, tap 3 = reflected column (W_2)
-        return torch.cat([wt, wt[2:3]], 0).to(dt)
-    if kind == "up":                                       # nearest-x2 + k3  ->  4-tap stride-2 conv over dy
-        return torch.stack([wt[2], wt[1] + wt[2], wt[0] + wt[1], wt[0]], 0).to(dt)
-    raise ValueError(kind)
-
-
 _CONV_KINDS = {
     # kind: fwd (stride, mode), dgrad (taps, stride, pad, mode)
     "same": dict(stride=1, mode=0),
@@ -136,7 +139,7 @@ def conv_forward(x, w, bias, cache: PackCache, kind: str, vp=None, **epi):
     k = w.shape[2] if w.dim() == 3 else 1
     Lout, stride, pad, mode = _conv_geom(kind, k, Lin)
     tag, vparams = _vkey(vp, w)
-    wp = cache.get(("f", kind, x.dtype, tag), vparams, lambda: pack_fwd(w, x.dtype))
+    wp = cache.packs(("p", kind, x.dtype, tag), vparams, w, kind, x.dtype)[0]
     return ops.gemm_nt(x, wp, bias, taps=k, lin=Lin, lout=Lout, stride=stride, pad=pad, mode=mode, out_shape=(B, Lout, wp.shape[1]), **epi)
 
 
@@ -145,7 +148,7 @@ def conv_dgrad(dy, w, cache: PackCache, kind: str, Lin: int, residual=None, vp=N
     B, Lout, Cout = dy.shape
     k = w.shape[2] if w.dim() == 3 else 1
     tag, vparams = _vkey(vp, w)
-    wp = cache.get(("d", kind, dy.dtype, tag), vparams, lambda: pack_dgrad(w, dy.dtype, kind))
+    wp = cache.packs(("p", kind, dy.dtype, tag), vparams, w, kind, dy.dtype)[1]
     Cin = wp.shape[1]
     if kind == "same":
         geom = dict(taps=k, stride=1, pad=k - 1 - k // 2, mode=0)
@@ -304,7 +307,7 @@ class FeedForwardFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, cache):
         h, pre = conv_forward(x, w1, b1, cache, "same", None, act=1, want_pre=True)
-        wp2 = cache.get(("f2", x.dtype), (w2,), lambda: pack_fwd(w2, x.dtype))
+        wp2 = cache.packs(("p2", x.dtype), (w2,), w2, "same", x.dtype)[0]
         out = ops.gemm_nt(h, wp2, b2, residual=x, out_shape=x.shape)
         ctx.save_for_backward(x, w1, w2, h, pre)
         ctx.cache, ctx.b1, ctx.b2 = cache, b1, b2
@@ -315,13 +318,13 @@ class FeedForwardFn(torch.autograd.Function):
         x, w1, w2, h, pre = ctx.saved_tensors
         dout = _rc(dout)
         cache = ctx.cache
-        wd2 = cache.get(("d2", x.dtype), (w2,), lambda: pack_dgrad(w2, x.dtype))
+        wd2 = cache.packs(("p2", x.dtype), (w2,), w2, "same", x.dtype)[1]
         dpre = ops.gemm_nt(dout, wd2, None, dact=pre, out_shape=pre.shape)          # (dout W2) * silu'(pre)
         dw2 = conv_wgrad(dout, h, w2, "same")
         db2 = _bias_grad(dout, ctx.b2)
         dw1 = conv_wgrad(dpre, x, w1, "same")
         db1 = _bias_grad(dpre, ctx.b1)
-        wd1 = cache.get(("d", "same", x.dtype), (w1,), lambda: pack_dgrad(w1, x.dtype))
+        wd1 = cache.packs(("p", "same", x.dtype, ""), (w1,), w1, "same", x.dtype)[1]
         dx = ops.gemm_nt(dpre, wd1, None, residual=dout, out_shape=x.shape)
         return dx, dw1, db1, dw2, db2, None
 
@@ -352,14 +355,14 @@ class AttentionFn(torch.autograd.Function):
         H, D = heads, dim_head
         dt = x.dtype
         xn, mr = ops.ln_fwd(x, nw, nb)
-        wqkv = cache.get(("qkv", dt), (wq, wkv), lambda: torch.cat([wq.detach(), wkv.detach()], 0).to(dt).unsqueeze(0))
+        wqkv = cache.packs(("qkv", dt), (wq, wkv), (wq, wkv), "same", dt)[0]
         qkv = ops.gemm_nt(xn, wqkv, None, out_shape=(B, N, (H + 2) * D))
         cos, sin = rope_tables(N, D, scale_base, x.device)
         qkv_r = ops.rope_cast(qkv, cos, sin, N, H + 1, H + 2, D)                # rotate q heads and k; cast v
         del qkv
         scale = D ** -0.5
         o, lse = ops.mqa_fwd(qkv_r, B, N, H, D, dt, scale)
-        wpo = cache.get(("fo", dt), (wo,), lambda: pack_fwd(wo, dt))
+        wpo = cache.packs(("po", dt), (wo,), wo, "same", dt)[0]
         out = ops.gemm_nt(o, wpo, bo, residual=xn, out_shape=x.shape)
         ctx.save_for_backward(x, nw, mr, xn, wq, wkv, wo, qkv_r, o, lse)
         ctx.cache, ctx.geom = cache, (H, D, scale_base, scale)
@@ -377,7 +380,7 @@ class AttentionFn(torch.autograd.Function):
         # to_out
         dwo = conv_wgrad(dout, o, wo, "same")
         dbo = _bias_grad(dout, ctx.bo)
-        wdo = cache.get(("do", dt), (wo,), lambda: pack_dgrad(wo, dt))
+        wdo = cache.packs(("po", dt), (wo,), wo, "same", dt)[1]
         do = ops.gemm_nt(dout, wdo, None, out_shape=o.shape)
         do16 = ops.cast_rows(do, torch.bfloat16)                                 # SDPA backward runs in bf16 (attention.py:101)
         # attention + rope
@@ -388,7 +391,7 @@ class AttentionFn(torch.autograd.Function):
         # to_q / to_kv
         dwq = conv_wgrad(dqkv[..., : H * D], xn, wq, "same")
         dwkv = conv_wgrad(dqkv[..., H * D:], xn, wkv, "same")
-        wdqkv = cache.get(("dqkv", dt), (wq, wkv), lambda: torch.cat([wq.detach(), wkv.detach()], 0).t().to(dt).unsqueeze(0))
+        wdqkv = cache.packs(("qkv", dt), (wq, wkv), (wq, wkv), "same", dt)[1]
         dxn = ops.gemm_nt(dqkv, wdqkv, None, residual=dout, out_shape=x.shape)   # + residual path (x + to_out(..), x = normed)
         tg, tb = grad_target(nw), grad_target(ctx.nb)
         direct_norm = tg is not None and tb is not None

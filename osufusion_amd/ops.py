@@ -369,6 +369,35 @@ def clip_coef(sumsq: torch.Tensor, max_norm: float, base: float, coef: torch.Ten
     call("osuf_clip_coef", _p(sumsq), float(max_norm), float(base), _p(coef), _p(total_norm), _stream())
 
 
+_DKIND = {"same": 0, "down": 1, "up": 2}
+
+
+def pack_weight(w: torch.Tensor, dtype: torch.dtype, kind: str = "same", want_fwd: bool = True, want_dgrad: bool = True,
+                fwd: Optional[torch.Tensor] = None, dgrad: Optional[torch.Tensor] = None, row_offset: int = 0):
+    """fp32 (O, I[, k]) master -> (fwd [k][O][I], dgrad [k'][I][O]) GEMM operands in `dtype`, one launch.  With fwd / dgrad
+    given, this weight's rows are written at row_offset of a larger stacked operand (the fused q|kv projection)."""
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda
+    O, I = w.shape[0], w.shape[1]
+    k = w.shape[2] if w.dim() == 3 else 1
+    kd = k if kind == "same" else 4
+    if want_fwd and fwd is None:
+        fwd = torch.empty((k, O, I), dtype=dtype, device=w.device)
+    if want_dgrad and dgrad is None:
+        dgrad = torch.empty((kd, I, O), dtype=dtype, device=w.device)
+    pf = pd = None
+    f_ld = f_ts = d_ld = d_ts = 0
+    if want_fwd:
+        assert fwd.dtype == dtype and fwd.is_contiguous() and fwd.shape[0] == k and fwd.shape[2] == I
+        f_ld, f_ts = I, fwd.shape[1] * I
+        pf = fwd.data_ptr() + row_offset * I * fwd.element_size()
+    if want_dgrad:
+        assert dgrad.dtype == dtype and dgrad.is_contiguous() and dgrad.shape[0] == kd and dgrad.shape[1] == I
+        d_ld, d_ts = dgrad.shape[2], I * dgrad.shape[2]
+        pd = dgrad.data_ptr() + row_offset * dgrad.element_size()
+    call("osuf_pack_weight", _p(w), O, I, k, 1 if dtype == torch.bfloat16 else 0, pf, f_ld, f_ts, pd, d_ld, d_ts, _DKIND[kind], _stream())
+    return (fwd if want_fwd else None), (dgrad if want_dgrad else None)
+
+
 def cast_f32_bf16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     call("osuf_cast_f32_bf16", _p(src), _p(dst), src.numel(), _stream())
     return dst

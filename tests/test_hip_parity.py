@@ -82,6 +82,34 @@ def test_mfma_layout_exact_integers(dtype):
     assert torch.equal(gw.double(), dy.double().t() @ a.double())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind,O,I,k", [("same", 40, 72, 3), ("same", 33, 17, 1), ("same", 64, 96, 15), ("same", 8, 40, 7), ("down", 48, 40, 3),
+                                        ("up", 24, 100, 3)])
+def test_pack_weight_kernel_bit_exact(dtype, kind, O, I, k):
+    """osuf_pack_weight vs its contract restated with torch ops: bit-exact (a cast at most, and for "up" one fp32 add)."""
+    w = T(uniform_pm(f"pack.{kind}.{O}.{I}.{k}", (O, I, k), 1.0))
+    if k == 1:
+        w = w[:, :, 0].contiguous()
+    fwd, dgr = ops.pack_weight(w, dtype, kind)
+    w3 = w if w.dim() == 3 else w.unsqueeze(-1)
+    ref_f = w3.permute(2, 0, 1).to(dtype)
+    wt = w3.permute(2, 1, 0)
+    if kind == "same":
+        ref_d = wt.flip(0).to(dtype)
+    elif kind == "down":
+        ref_d = torch.cat([wt, wt[2:3]], 0).to(dtype)
+    else:
+        ref_d = torch.stack([wt[2], wt[1] + wt[2], wt[0] + wt[1], wt[0]], 0).to(dtype)
+    assert torch.equal(fwd, ref_f.contiguous()) and torch.equal(dgr, ref_d.contiguous())
+    # two weights stacked along O (fused q|kv projection operands)
+    if k == 1:
+        w2 = T(uniform_pm("pack.second", (24, I), 1.0))
+        cache = Fn.PackCache()
+        f2, d2 = cache.packs(("t", dtype), (w, w2), (w, w2), "same", dtype)
+        cat = torch.cat([w, w2], 0)
+        assert torch.equal(f2[0], cat.to(dtype)) and torch.equal(d2[0], cat.t().contiguous().to(dtype))
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("kind,k,L", [("same", 3, 96), ("same", 1, 64), ("same", 7, 40), ("same", 15, 200), ("down", 3, 96), ("up", 3, 56),
                                       ("same", 3, 8), ("down", 3, 300)])

@@ -80,10 +80,38 @@ def emu_gemm_tn(dy, x, *, taps=1, lin=None, lout=None, stride=1, pad=0, mode=0, 
     return res
 
 
+def emu_pack_weight(w, dtype, kind="same", want_fwd=True, want_dgrad=True, fwd=None, dgrad=None, row_offset=0):
+    """osuf_pack_weight's contract (include/osufusion_hip.h), element by element."""
+    w3 = w if w.dim() == 3 else w.unsqueeze(-1)
+    O, I, k = w3.shape
+    kd = k if kind == "same" else 4
+    if want_fwd and fwd is None:
+        fwd = torch.zeros(k, O, I, dtype=dtype)
+    if want_dgrad and dgrad is None:
+        dgrad = torch.zeros(kd, I, O, dtype=dtype)
+    for o in range(O):
+        for i in range(I):
+            taps = [float(w3[o, i, t]) for t in range(k)]
+            if want_fwd:
+                for t in range(k):
+                    fwd[t, row_offset + o, i] = taps[t]
+            if want_dgrad:
+                if kind == "same":
+                    vals = [taps[k - 1 - t] for t in range(k)]
+                elif kind == "down":
+                    vals = [taps[0], taps[1], taps[2], taps[2]]
+                else:
+                    vals = [taps[2], taps[1] + taps[2], taps[0] + taps[1], taps[0]]
+                for t, v in enumerate(vals):
+                    dgrad[t, i, row_offset + o] = v
+    return (fwd if want_fwd else None), (dgrad if want_dgrad else None)
+
+
 @pytest.fixture()
 def emulated(monkeypatch):
     monkeypatch.setattr(ops, "gemm_nt", emu_gemm_nt)
     monkeypatch.setattr(ops, "gemm_tn", emu_gemm_tn)
+    monkeypatch.setattr(ops, "pack_weight", emu_pack_weight)
 
 
 @pytest.mark.parametrize("kind,k,L", [("same", 3, 12), ("same", 1, 9), ("same", 7, 10), ("same", 15, 20), ("down", 3, 12), ("down", 3, 2),
