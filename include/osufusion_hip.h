@@ -133,6 +133,13 @@ int osuf_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t stream);
 int osuf_pack_weight(const float* w, int O, int I, int k, int out_dtype, void* F, long f_ld, long f_tapstride, void* D, long d_ld,
                      long d_tapstride, int dkind, hipStream_t stream);
 
+/* LoRA / DoRA adapters folded into an effective weight (reference: osu_fusion/modules/lora_layers.py:16-26 get_weight_norm,
+ * :72-92 DoraConv1dLayer.forward, :284-298 get_delta_weight; peft 0.12 DoraLinearLayer for attn.to_q / attn.to_kv as wired at
+ * trainer_peft.py:236-244).  W (O, IK) fp32 frozen base, A (r, IK), B (O, r), mag (O) or NULL for plain LoRA, IK = in*k:
+ *   V = W + scaling * B A;   g = mag / ||V||_row  (1 without mag);   Weff = g * V.   g (O floats) may be NULL. */
+int osuf_dora_effective(const float* W, const float* A, const float* B, const float* mag, int O, int IK, int r, float scaling,
+                        float* Weff, float* g, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

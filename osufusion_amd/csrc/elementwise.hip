@@ -348,4 +348,50 @@ extern "C" int osuf_pack_weight(const float* w, int O, int I, int k, int out_dty
   return osuf_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------
+// LoRA / DoRA effective weight (modules/lora_layers.py:16-26,72-92; peft 0.12 DoraLinearLayer):
+//   V[o][j]   = W[o][j] + s * sum_r B[o][r] * A[r][j]           j over (in, tap), r ascending, fp32 FMA chain
+//   DoRA:  g[o] = m[o] / ||V[o][:]||_2 ,  Weff = g[o] * V        (the norm is a constant of the step: detached in the reference)
+//   LoRA:  g[o] = 1 ,                     Weff = V
+// so that  base(x) + (g-1)*conv(x,W) + g*s*B(A(x))  ==  conv(x, Weff) + bias  -- the forward and the input gradient then run
+// the unchanged conv / linear GEMMs on Weff; only the adapter gradients use the factored form (functional.adapter_grads).
+// One block per output channel; the row lives in LDS between the norm and the scale pass.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dora_effective_kernel(const float* __restrict__ W, const float* __restrict__ A, const float* __restrict__ Bm,
+                                                             const float* __restrict__ mag, int IK, int r, float s, float* __restrict__ Weff,
+                                                             float* __restrict__ g_out) {
+  extern __shared__ float row[];                            // IK floats + 4 partials
+  __shared__ float part[4];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  const float* w = W + (long)o * IK;
+  const float* b = Bm + (long)o * r;
+  float ss = 0.f;
+  for (int j = tid; j < IK; j += 256) {
+    float acc = 0.f;
+    for (int q = 0; q < r; ++q) acc = fmaf(b[q], A[(long)q * IK + j], acc);
+    const float v = fmaf(s, acc, w[j]);
+    row[j] = v;
+    ss = fmaf(v, v, ss);
+  }
+  float g = 1.f;
+  if (mag) {
+    ss = group_sum<64>(ss);
+    if ((tid & 63) == 0) part[tid >> 6] = ss;
+    __syncthreads();
+    const float tot = part[0] + part[1] + part[2] + part[3];
+    g = mag[o] / sqrtf(tot);
+  }
+  if (tid == 0 && g_out) g_out[o] = g;
+  for (int j = tid; j < IK; j += 256) Weff[(long)o * IK + j] = g * row[j];   // each thread re-reads only what it wrote
+}
+
+extern "C" int osuf_dora_effective(const float* W, const float* A, const float* B, const float* mag, int O, int IK, int r, float scaling,
+                                   float* Weff, float* g, hipStream_t stream) {
+  if (!W || !A || !B || !Weff || O <= 0 || IK <= 0 || r <= 0 || (long)IK * 4 > 150 * 1024) return OSUF_EINVAL;
+  const int lds = IK * 4;
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dora_effective_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(dora_effective_kernel, dim3(O), dim3(256), lds, stream, W, A, B, mag, IK, r, scaling, Weff, g);
+  return osuf_launch_status();
+}
+
 extern "C" int osuf_version(void) { return 1; }

@@ -175,6 +175,68 @@ def conv_wgrad(dy, x, w, kind: str, direct: bool = True):
     return g if conv else g[0]
 
 
+# ---- LoRA / DoRA adapters (modules/lora_layers.py; §8f row 2) ------------------------------------------------
+class Adapter:
+    """Frozen base weight + (lora_A, lora_B[, DoRA magnitude]) of one adapted Conv1d / Linear.
+
+    The reference evaluates  base(x) + (g-1)*conv(x,W) + g*s*B(A(x)),  g = m/||W + s*BA|| (norm detached)
+    (lora_layers.py:72-92) -- three convolutions per layer.  With the norm a constant of the step this is exactly
+    conv(x, Weff) + bias with Weff = g*(W + s*BA), so here the forward and the input gradient run the SAME single GEMM as the
+    un-adapted layer on an effective weight rebuilt once per optimizer step (osuf_dora_effective), and only the adapter
+    gradients use the factored rank-r form (adapter_grads): no full-size weight gradient is ever formed."""
+
+    def __init__(self, base_weight, lora_a, lora_b, magnitude, scaling: float) -> None:
+        self.w, self.a, self.b, self.m, self.scaling = base_weight, lora_a, lora_b, magnitude, float(scaling)
+        self._eff = None
+
+    @property
+    def params(self) -> Tuple[torch.Tensor, ...]:
+        return (self.w, self.a, self.b) + ((self.m,) if self.m is not None else ())
+
+    def effective(self):
+        """-> (Weff like w, g (O,)); cached until a source parameter changes."""
+        ver = (_WEIGHT_EPOCH, *[(p._version, p.data_ptr()) for p in self.params])
+        if self._eff is None or self._eff[0] != ver:
+            with torch.no_grad():
+                m = self.m.detach().float().reshape(-1).contiguous() if self.m is not None else None
+                weff, g = ops.dora_effective(self.w.detach().float().contiguous(), self.a.detach().float().contiguous(),
+                                             self.b.detach().float().contiguous(), m, self.scaling)
+            self._eff = (ver, weff, g)
+        return self._eff[1], self._eff[2]
+
+
+def adapter_grads(ad: Adapter, dy, x, y, bias, kind: str, cache: PackCache):
+    """Gradients of (lora_A, lora_B, magnitude) from rows dy (B, Lout, O), the layer input x (B, Lin, I) and the layer output
+    y (B, Lout, O) (= g*z + bias, as produced by the forward).  All GEMMs are rank-r:
+        u  = A(x)                       (B, Lout, r)   tap-GEMM, N = r
+        du = dy . (s g B)               (B, Lout, r)   K = O
+        dB = s g (dy^T u),  dA = du^T x (per tap),  dm = (sum dy*y - bias * sum dy) / m      [g = m/norm, norm detached]"""
+    B_, Lin, I = x.shape
+    O = dy.shape[-1]
+    r = ad.a.shape[0]
+    conv = ad.a.dim() == 3
+    k = ad.a.shape[2] if conv else 1
+    dt = x.dtype
+    _, g = ad.effective()
+    Lout, stride, pad, mode = _conv_geom(kind, k, Lin)
+    with torch.no_grad():
+        pa = cache.packs(("lora_a", id(ad), kind, dt), (ad.a,), ad.a, "same", dt)[0]                       # [k][r][I]
+        sg = g * ad.scaling
+        pbt = cache.packs(("lora_bt", id(ad), dt), ad.params, (ad.b.detach().float().reshape(O, r) * sg[:, None]), "same", dt)[1]   # [1][r][O]
+        u = ops.gemm_nt(x, pa, None, taps=k, lin=Lin, lout=Lout, stride=stride, pad=pad, mode=mode, out_shape=(B_, Lout, r))
+        du = ops.gemm_nt(dy, pbt, None, out_shape=(B_, Lout, r))
+        db = ops.gemm_tn(dy, u, n1=O)[0] * sg[:, None]                                             # (O, r)
+        da = ops.gemm_tn(du, x, taps=k, lin=Lin, lout=Lout, stride=stride, pad=pad, mode=mode, n1=r, conv_layout=conv)
+        da = da if conv else da[0]
+        dm = None
+        if ad.m is not None:
+            s1 = ops.wcolsum(dy, y, None, B_, Lout).sum(0)
+            if bias is not None:
+                s1 = s1 - bias.detach().float() * ops.colsum(dy, O)
+            dm = (s1 / ad.m.detach().float().reshape(-1)).reshape(ad.m.shape)
+    return da.reshape(ad.a.shape), db.reshape(ad.b.shape), dm
+
+
 # ---------------------------------------------------------------------------------------------------------
 class ConvFn(torch.autograd.Function):
     """Conv1d (same / Downsample / Upsample geometry) or Linear on rows.  unet.py:61-101, residual.py:115."""
@@ -196,20 +258,48 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
-class BlockFn(torch.autograd.Function):
-    """conv k3 -> GroupNorm(1,C) -> FiLM -> SiLU   (residual.py:75-84).  ss: fp32 (B, 2C) = (scale | shift) or None."""
+class AdaptedConvFn(torch.autograd.Function):
+    """A LoRA / DoRA-adapted Conv1d / Linear on rows, on its own (lora_layers.py:312-328): one GEMM on the effective weight."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, gamma, beta, ss, cache):
+    def forward(ctx, x, bias, cache, kind, adapter, la, lb, lm):
+        y = conv_forward(x, adapter.effective()[0], bias, cache, kind, ("dora", *adapter.params))
+        ctx.save_for_backward(x, y)
+        ctx.cache, ctx.kind, ctx.adapter, ctx.bias_ref = cache, kind, adapter, bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        ad, need = ctx.adapter, ctx.needs_input_grad
+        dy = _rc(dy)
+        dx = conv_dgrad(dy, ad.effective()[0], ctx.cache, ctx.kind, x.shape[1], vp=("dora", *ad.params)) if need[0] else None
+        db = _bias_grad(dy, ctx.bias_ref, dy.shape[-1]) if ctx.bias_ref is not None and need[1] else None
+        da = dlb = dm = None
+        if need[5] or need[6] or need[7]:
+            da, dlb, dm = adapter_grads(ad, dy, x, y, ctx.bias_ref, ctx.kind, ctx.cache)
+        return dx, db, None, None, None, da, dlb, dm
+
+
+class BlockFn(torch.autograd.Function):
+    """conv k3 -> GroupNorm(1,C) -> FiLM -> SiLU   (residual.py:75-84).  ss: fp32 (B, 2C) = (scale | shift) or None.
+    adapter (+ its parameters la, lb, lm as autograd inputs): LoRA / DoRA on the conv (block{1,2}.proj, trainer_peft.py:241)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, gamma, beta, ss, cache, adapter=None, la=None, lb=None, lm=None):
         B, L, _ = x.shape
         C = w.shape[0]
         stats = torch.zeros((B, 2), dtype=torch.float64, device=x.device)
-        y = conv_forward(x, w, bias, cache, "same", None, stats=stats)
+        if adapter is not None:
+            weff, _ = adapter.effective()
+            y = conv_forward(x, weff, bias, cache, "same", ("dora", *adapter.params), stats=stats)
+        else:
+            y = conv_forward(x, w, bias, cache, "same", None, stats=stats)
         mr = ops.gn_finalize(stats, L * C)
         ssc = ss.contiguous() if ss is not None else None
         h = ops.gn_apply(y, mr, gamma, beta, ssc, L)
         ctx.save_for_backward(x, w, y, mr, gamma, beta, ssc if ssc is not None else mr)
-        ctx.cache, ctx.has_ss = cache, ss is not None
+        ctx.cache, ctx.has_ss, ctx.adapter = cache, ss is not None, adapter
         ctx.bias_ref = bias
         return h
 
@@ -218,16 +308,24 @@ class BlockFn(torch.autograd.Function):
         x, w, y, mr, gamma, beta, ss = ctx.saved_tensors
         ss = ss if ctx.has_ss else None
         L = x.shape[1]
+        need = ctx.needs_input_grad
         tg, tb = grad_target(gamma), grad_target(beta)
         direct_norm = tg is not None and tb is not None
         dy, dgamma, dbeta, dss = ops.gn_bwd(_rc(dh), y, mr, gamma, beta, ss, L, tg if direct_norm else None, tb if direct_norm else None)
         if direct_norm:
             grad_done(gamma); grad_done(beta)
             dgamma = dbeta = None
-        dx = conv_dgrad(dy, w, ctx.cache, "same", L) if ctx.needs_input_grad[0] else None
-        dw = conv_wgrad(dy, x, w, "same")
-        db = _bias_grad(dy, ctx.bias_ref)
-        return dx, dw, db, dgamma, dbeta, dss, None
+        ad = ctx.adapter
+        dx = None
+        if need[0]:
+            dx = conv_dgrad(dy, ad.effective()[0], ctx.cache, "same", L, vp=("dora", *ad.params)) if ad is not None \
+                else conv_dgrad(dy, w, ctx.cache, "same", L)
+        dw = conv_wgrad(dy, x, w, "same") if need[1] else None
+        db = _bias_grad(dy, ctx.bias_ref) if need[2] else None
+        da = dlb = dm = None
+        if ad is not None and (need[8] or need[9] or need[10]):
+            da, dlb, dm = adapter_grads(ad, dy, x, y, ctx.bias_ref, "same", ctx.cache)
+        return dx, dw, db, dgamma if need[3] else None, dbeta if need[4] else None, dss, None, None, da, dlb, dm
 
 
 class GCAPoolFn(torch.autograd.Function):
@@ -253,9 +351,9 @@ class GCAPoolFn(torch.autograd.Function):
         zero_gate = torch.zeros((B, C), dtype=torch.float32, device=h.device)
         # dh = p*dpooled + dlogit*wk  (the `dout*gate` term of the fused kernel is disabled with a zero gate)
         dh, dlogit = ops.gca_bwd_apply(h, h, p, zero_gate, dpooled, sdot, wkv, L)
-        dwk = ops.wcolsum(h, None, dlogit, B, L).sum(0)
-        dbk = dlogit.sum().reshape(1)
-        return dh, dwk.reshape(ctx.wshape), dbk
+        dwk = ops.wcolsum(h, None, dlogit, B, L).sum(0).reshape(ctx.wshape) if ctx.needs_input_grad[1] else None   # frozen base: skip the pass
+        dbk = dlogit.sum().reshape(1) if ctx.needs_input_grad[2] else None
+        return dh, dwk, dbk
 
 
 class GateResFn(torch.autograd.Function):
@@ -296,8 +394,8 @@ class GateResConvFn(torch.autograd.Function):
         dgate = ops.wcolsum(dout, h, None, B, L)
         dh = ops.gate_residual(dout, gate, None, L)
         dx = conv_dgrad(dout, w, ctx.cache, "same", L)
-        dw = conv_wgrad(dout, x, w, "same")
-        db = _bias_grad(dout, ctx.bias_ref)
+        dw = conv_wgrad(dout, x, w, "same") if ctx.needs_input_grad[3] else None
+        db = _bias_grad(dout, ctx.bias_ref) if ctx.needs_input_grad[4] else None
         return dh, dgate, dx, dw, db, None
 
 
@@ -320,10 +418,11 @@ class FeedForwardFn(torch.autograd.Function):
         cache = ctx.cache
         wd2 = cache.packs(("p2", x.dtype), (w2,), w2, "same", x.dtype)[1]
         dpre = ops.gemm_nt(dout, wd2, None, dact=pre, out_shape=pre.shape)          # (dout W2) * silu'(pre)
-        dw2 = conv_wgrad(dout, h, w2, "same")
-        db2 = _bias_grad(dout, ctx.b2)
-        dw1 = conv_wgrad(dpre, x, w1, "same")
-        db1 = _bias_grad(dpre, ctx.b1)
+        need = ctx.needs_input_grad
+        dw2 = conv_wgrad(dout, h, w2, "same") if need[3] else None
+        db2 = _bias_grad(dout, ctx.b2) if need[4] else None
+        dw1 = conv_wgrad(dpre, x, w1, "same") if need[1] else None
+        db1 = _bias_grad(dpre, ctx.b1) if need[2] else None
         wd1 = cache.packs(("p", "same", x.dtype, ""), (w1,), w1, "same", x.dtype)[1]
         dx = ops.gemm_nt(dpre, wd1, None, residual=dout, out_shape=x.shape)
         return dx, dw1, db1, dw2, db2, None
@@ -347,15 +446,17 @@ def rope_tables(n: int, dim: int, scale_base: int, device, theta: float = 10000.
 
 
 class AttentionFn(torch.autograd.Function):
-    """LayerNorm -> to_q/to_kv -> RoPE -> MQA flash attention -> to_out + residual(normed x)   (unet.py:125-141)."""
+    """LayerNorm -> to_q/to_kv -> RoPE -> MQA flash attention -> to_out + residual(normed x)   (unet.py:125-141).
+    aq / akv: LoRA / DoRA adapters on to_q / to_kv (trainer_peft.py:241), their parameters passed as autograd inputs."""
 
     @staticmethod
-    def forward(ctx, x, nw, nb, wq, wkv, wo, bo, cache, heads, dim_head, scale_base):
+    def forward(ctx, x, nw, nb, wq, wkv, wo, bo, cache, heads, dim_head, scale_base, aq=None, akv=None,
+                qa=None, qb=None, qm=None, kva=None, kvb=None, kvm=None):
         B, N, C = x.shape
         H, D = heads, dim_head
         dt = x.dtype
         xn, mr = ops.ln_fwd(x, nw, nb)
-        wqkv = cache.packs(("qkv", dt), (wq, wkv), (wq, wkv), "same", dt)[0]
+        wqkv = AttentionFn._qkv_packs(cache, dt, wq, wkv, aq, akv)[0]
         qkv = ops.gemm_nt(xn, wqkv, None, out_shape=(B, N, (H + 2) * D))
         cos, sin = rope_tables(N, D, scale_base, x.device)
         qkv_r = ops.rope_cast(qkv, cos, sin, N, H + 1, H + 2, D)                # rotate q heads and k; cast v
@@ -367,19 +468,30 @@ class AttentionFn(torch.autograd.Function):
         ctx.save_for_backward(x, nw, mr, xn, wq, wkv, wo, qkv_r, o, lse)
         ctx.cache, ctx.geom = cache, (H, D, scale_base, scale)
         ctx.nb, ctx.bo = nb, bo
+        ctx.aq, ctx.akv = aq, akv
         return out
+
+    @staticmethod
+    def _qkv_packs(cache, dt, wq, wkv, aq, akv):
+        """Stacked (q | kv) projection operands; adapted halves use their effective weight."""
+        if aq is None and akv is None:
+            return cache.packs(("qkv", dt), (wq, wkv), (wq, wkv), "same", dt)
+        ws = (aq.effective()[0] if aq is not None else wq, akv.effective()[0] if akv is not None else wkv)
+        params = (wq, wkv) + (aq.params if aq is not None else ()) + (akv.params if akv is not None else ())
+        return cache.packs(("qkv_dora", dt), params, ws, "same", dt)
 
     @staticmethod
     def backward(ctx, dout):
         x, nw, mr, xn, wq, wkv, wo, qkv_r, o, lse = ctx.saved_tensors
         H, D, scale_base, scale = ctx.geom
         cache = ctx.cache
+        need = ctx.needs_input_grad
         B, N, C = x.shape
         dt = x.dtype
         dout = _rc(dout)
         # to_out
-        dwo = conv_wgrad(dout, o, wo, "same")
-        dbo = _bias_grad(dout, ctx.bo)
+        dwo = conv_wgrad(dout, o, wo, "same") if need[5] else None
+        dbo = _bias_grad(dout, ctx.bo) if need[6] else None
         wdo = cache.packs(("po", dt), (wo,), wo, "same", dt)[1]
         do = ops.gemm_nt(dout, wdo, None, out_shape=o.shape)
         do16 = ops.cast_rows(do, torch.bfloat16)                                 # SDPA backward runs in bf16 (attention.py:101)
@@ -389,17 +501,27 @@ class AttentionFn(torch.autograd.Function):
         dqkv = ops.rope_bwd(dqkv32, dt, cos, sin, N, H + 1, H + 2, D)
         del dqkv32
         # to_q / to_kv
-        dwq = conv_wgrad(dqkv[..., : H * D], xn, wq, "same")
-        dwkv = conv_wgrad(dqkv[..., H * D:], xn, wkv, "same")
-        wdqkv = cache.packs(("qkv", dt), (wq, wkv), (wq, wkv), "same", dt)[1]
-        dxn = ops.gemm_nt(dqkv, wdqkv, None, residual=dout, out_shape=x.shape)   # + residual path (x + to_out(..), x = normed)
+        dwq = conv_wgrad(dqkv[..., : H * D], xn, wq, "same") if need[3] else None
+        dwkv = conv_wgrad(dqkv[..., H * D:], xn, wkv, "same") if need[4] else None
+        aq, akv = ctx.aq, ctx.akv
+        packs = AttentionFn._qkv_packs(cache, dt, wq, wkv, aq, akv)
+        gq = gkv = (None, None, None)
+        if (aq is not None and any(need[13:16])) or (akv is not None and any(need[16:19])):
+            qkv = ops.gemm_nt(xn, packs[0], None, out_shape=(B, N, (H + 2) * D))     # pre-RoPE projections again (for d magnitude)
+            if aq is not None:
+                gq = adapter_grads(aq, dqkv[..., : H * D], xn, qkv[..., : H * D], None, "same", cache)
+            if akv is not None:
+                gkv = adapter_grads(akv, dqkv[..., H * D:], xn, qkv[..., H * D:], None, "same", cache)
+            del qkv
+        dxn = ops.gemm_nt(dqkv, packs[1], None, residual=dout, out_shape=x.shape)   # + residual path (x + to_out(..), x = normed)
         tg, tb = grad_target(nw), grad_target(ctx.nb)
         direct_norm = tg is not None and tb is not None
         dx, dnw, dnb = ops.ln_bwd(dxn, x, mr, nw, tg if direct_norm else None, tb if direct_norm else None)
         if direct_norm:
             grad_done(nw); grad_done(ctx.nb)
             dnw = dnb = None
-        return dx, dnw, dnb, dwq, dwkv, dwo, dbo, None, None, None, None
+        return (dx, dnw if need[1] else None, dnb if need[2] else None, dwq, dwkv, dwo, dbo, None, None, None, None, None, None,
+                *gq, *gkv)
 
 
 class RowsFromNCLFn(torch.autograd.Function):

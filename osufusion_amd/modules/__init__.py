@@ -1,1 +1,1 @@
-from . import attention, residual, unet, utils  # noqa: F401
+from . import attention, lora_layers, residual, unet, utils  # noqa: F401

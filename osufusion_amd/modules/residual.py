@@ -54,7 +54,8 @@ class Block(nn.Module):
         self._cache = Fn.PackCache()
 
     def forward_rows(self, x: torch.Tensor, ss: Optional[torch.Tensor]) -> torch.Tensor:
-        return Fn.BlockFn.apply(x, self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias, ss, self._cache)
+        extra = self.proj.adapter_inputs() if hasattr(self.proj, "adapter_inputs") else ()      # lora_layers.LoraConv1d
+        return Fn.BlockFn.apply(x, self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias, ss, self._cache, *extra)
 
     def forward(self, x: torch.Tensor, scale_shift: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
         rows = rt.to_rows(x, rt.compute_dtype(self.proj.weight.dtype))

@@ -157,8 +157,14 @@ class Attention(nn.Module):
         if self.kv_heads != 1 or self.dim_head != 64:
             raise NotImplementedError(f"HIP attention is MQA with head_dim 64 (got kv_heads={self.kv_heads}, dim_head={self.dim_head})")
         x = rt.cast_rows(x.contiguous(), rt.compute_dtype(self.to_q.weight.dtype))
+        extra = ()
+        if hasattr(self.to_q, "adapter_inputs") or hasattr(self.to_kv, "adapter_inputs"):                # lora_layers.LoraLinear
+            none4 = (None, None, None, None)
+            aq, qa, qb, qm = self.to_q.adapter_inputs() if hasattr(self.to_q, "adapter_inputs") else none4
+            akv, ka, kb, km = self.to_kv.adapter_inputs() if hasattr(self.to_kv, "adapter_inputs") else none4
+            extra = (aq, akv, qa, qb, qm, ka, kb, km)
         return Fn.AttentionFn.apply(x, self.norm.weight, self.norm.bias, self.to_q.weight, self.to_kv.weight, self.to_out.weight,
-                                    self.to_out.bias, self._cache, self.heads, self.dim_head, self.context_len)
+                                    self.to_out.bias, self._cache, self.heads, self.dim_head, self.context_len, *extra)
 
 
 class FeedForward(nn.Sequential):

@@ -398,6 +398,22 @@ def pack_weight(w: torch.Tensor, dtype: torch.dtype, kind: str = "same", want_fw
     return (fwd if want_fwd else None), (dgrad if want_dgrad else None)
 
 
+def dora_effective(w: torch.Tensor, a: torch.Tensor, b: torch.Tensor, mag: Optional[torch.Tensor], scaling: float):
+    """(Weff shaped like w, g (O,)) from the frozen base w (O, I[, k]), lora_A (r, I[, k]), lora_B (O, r[, 1]) and the DoRA magnitude
+    (O values, any shape) or None for plain LoRA."""
+    for t in (w, a, b):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+    O, r = w.shape[0], a.shape[0]
+    IK = w.numel() // O
+    assert a.numel() == r * IK and b.numel() == O * r
+    if mag is not None:
+        assert mag.dtype == torch.float32 and mag.is_contiguous() and mag.numel() == O
+    weff = torch.empty_like(w)
+    g = torch.empty(O, dtype=torch.float32, device=w.device)
+    call("osuf_dora_effective", _p(w), _p(a), _p(b), _p(mag), O, IK, r, float(scaling), _p(weff), _p(g), _stream())
+    return weff, g
+
+
 def cast_f32_bf16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     call("osuf_cast_f32_bf16", _p(src), _p(dst), src.numel(), _stream())
     return dst
