@@ -99,6 +99,9 @@ def main() -> None:
     ap.add_argument("--length", type=int, default=LENGTH)
     ap.add_argument("--dim-h", type=int, default=DIM_H)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lora", type=int, default=0, metavar="R",
+                    help="BASELINE config 5 instead of the headline metric: DoRA rank-R adapters on attn.to_q/to_kv and "
+                         "block{1,2}.proj (trainer_peft.py:236-244), base frozen; the reference runs R=32, config 5 says 16")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -122,6 +125,12 @@ def main() -> None:
     from osufusion_amd.train import Trainer
 
     model = build_model(device, args.dim_h)
+    if args.lora:
+        from osufusion_amd.modules import lora_layers as LL
+        LL.get_peft_model(model, LL.LoraConfig(r=args.lora, lora_alpha=args.lora, use_dora=True))
+        with torch.no_grad():                              # peft zero-inits lora_B: give it life so every adapter gradient is exercised
+            for m in LL.lora_modules(model):
+                m.lora_B["default"].weight.normal_(0.0, 0.02)
     trainer = Trainer(model, lr=1e-4, weight_decay=1e-2, clip_grad_norm=1.0, compute_dtype=torch.bfloat16)
     x, a, c, noise, t = synth_batch(rank, device, args.batch, args.length)
 
@@ -169,18 +178,24 @@ def main() -> None:
                         mean_launch_ms=round(stats[dom]["total_ms"] / stats[dom]["launches"], 3),
                         step_frac_of_peak=round(STEP_TFLOP / (ms / 1e3) / MFMA_BF16_PEAK_TFLOPS, 4) if full else None,
                         all_kernels_ms_per_step={k: round(v["total_ms"] / args.steps, 2) for k, v in stats.items()})
+        metric = "denoise-steps/sec (train fwd+bwd) at B=32 L=4096"
+        if args.lora:
+            metric = f"DoRA r={args.lora} fine-tune steps/sec at B={args.batch} L={args.length} (BASELINE config 5, per-GPU shard)"
+            value = world * args.steps / elapsed
         out = {
-            "metric": "denoise-steps/sec (train fwd+bwd) at B=32 L=4096", "value": round(value, 4), "unit": "steps/s", "n_gpus": world,
+            "metric": metric, "value": round(value, 4), "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (SURVEY 8d shapes; random-init weights, live final_conv)",
-            "config": {"workload": f"full OsuFusion UNet dim_h={args.dim_h} (343.5M params) train step: fwd+bwd+grad-norm+clip+AdamW"
+            "config": {"workload": (f"trainer_peft path: frozen base + DoRA r={args.lora} on attn.to_q/to_kv/block1.proj/block2.proj "
+                                    f"({trainer.flat.numel / 1e6:.1f}M trainable); " if args.lora else "") +
+                                   f"full OsuFusion UNet dim_h={args.dim_h} (343.5M params) train step: fwd+bwd+grad-norm+clip+AdamW"
                                    f"{'+RCCL all-reduce' if world > 1 else ''}, per-GPU batch {args.batch}, L={args.length}, x (B,6,L), "
                                    f"audio (B,96,L) [BASELINE 'audio-ctx=1024x128' maps to the (B,1024,L/8) bottleneck code]",
                        "global_batch": args.batch * world, "seq_len": args.length, "parallelism": f"dp{world}"},
             "loss": round(loss.item(), 5), "grad_norm": round(gnorm.item(), 4),
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.lora:
             out["cpu_baseline"] = cpu_baseline(model, args.length, args.cpu_threads or host_threads())
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)

@@ -340,7 +340,9 @@ __global__ __launch_bounds__(NW * 64) void mqa_bwd_dq_kernel(AttnArgs a) {
 // backward, dK/dV: key-stationary.  A wave owns 32 keys; the workgroup (8 waves = 256 keys) sweeps every
 // (head, 32-query block) pair, staging Q / dO / lse / delta of the pair in LDS for all waves.
 // ------------------------------------------------------------------------------------------------------
-template <int NW>
+// DBG (triage builds via OSUF_ATTN_DBG, results garbage unless 0): 1 = no stage loads/stores (stage 0 reused), 2 = 1 + no barrier,
+// 3 = no softmax VALU, 4 = no LDS fragment reads, 5 = no MFMA.
+template <int NW, int DBG = 0>
 __global__ __launch_bounds__(NW * 64) void mqa_bwd_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][Q 4K | dO 4K | lse 128 | delta 128]
   constexpr int kStage = 4096 + 4096 + 256;
@@ -416,31 +418,41 @@ __global__ __launch_bounds__(NW * 64) void mqa_bwd_dkv_kernel(AttnArgs a) {
   load_stage(0);
   store_stage(0);
   __syncthreads();
+  bf16x8 cfrag = __builtin_bit_cast(bf16x8, u32x4{(uint32_t)lane, 1u, 2u, 3u});
   for (int it = 0; it < niter; ++it) {
-    const char* qs = smem + (it & 1) * kStage;
+    const char* qs = smem + ((DBG == 1 || DBG == 2) ? 0 : (it & 1)) * kStage;
     const char* dos = qs + 4096;
     const float* ls = reinterpret_cast<const float*>(qs + 8192);
-    if (it + 1 < niter) load_stage(it + 1);
+    if (DBG != 1 && DBG != 2 && it + 1 < niter) load_stage(it + 1);
     // S[q][key] = Q K^T ; dP[q][key] = dO V^T    (q rows in registers, key on the lane)
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    if (DBG == 4) asm volatile("" : "+v"(cfrag));
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(qs, lo, ks, 0), kf[ks], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(dos, lo, ks, 0), vf[ks], dp, 0, 0, 0);
+      const bf16x8 fq = DBG == 4 ? cfrag : lds_row_frag(qs, lo, ks, 0);
+      const bf16x8 fo = DBG == 4 ? cfrag : lds_row_frag(dos, lo, ks, 0);
+      if (DBG == 5) { asm volatile("" ::"v"(fq), "v"(fo)); continue; }
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq, kf[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo, vf[ks], dp, 0, 0, 0);
     }
+    if (DBG == 5) asm volatile("" : "+v"(s), "+v"(dp));
     f32x16 ds;
+    if (DBG == 3) {
+      ds = dp;
+    } else {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 l4 = *reinterpret_cast<const f32x4*>(ls + 8 * g + 4 * lh);
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(ls + 32 + 8 * g + 4 * lh);
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(ls + 8 * g + 4 * lh);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(ls + 32 + 8 * g + 4 * lh);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
-        float p = fast_exp2(fmaf(s[r], c, -l4[e]));
-        s[r] = p;
-        ds[r] = p * (dp[r] - d4[e]) * a.scale;
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          float p = fast_exp2(fmaf(s[r], c, -l4[e]));
+          s[r] = p;
+          ds[r] = p * (dp[r] - d4[e]) * a.scale;
+        }
       }
     }
     // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]
@@ -450,12 +462,199 @@ __global__ __launch_bounds__(NW * 64) void mqa_bwd_dkv_kernel(AttnArgs a) {
       const bf16x8 df = acc_to_frag(ds, s2);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(dos, lo, s2 * 16, dt), pf, dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(qs, lo, s2 * 16, dt), df, dk[dt], 0, 0, 0);
+        const bf16x8 fo = DBG == 4 ? cfrag : lds_tr_frag(dos, lo, s2 * 16, dt);
+        const bf16x8 fq = DBG == 4 ? cfrag : lds_tr_frag(qs, lo, s2 * 16, dt);
+        if (DBG == 5) { asm volatile("" ::"v"(fq), "v"(fo), "v"(pf), "v"(df)); continue; }
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo, pf, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq, df, dk[dt], 0, 0, 0);
       }
     }
-    if (it + 1 < niter) store_stage((it + 1) & 1);
+    if (DBG != 1 && DBG != 2 && it + 1 < niter) store_stage((it + 1) & 1);
+    if (DBG != 2) __syncthreads();
+  }
+  if (kok) {
+    const long m = (long)b * a.N + key;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = dt * 32 + 8 * g + 4 * lh;
+        float k4[4] = {dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]};
+        float v4[4] = {dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]};
+        store4(a.dk + m * a.lddk + d0, k4);
+        store4(a.dv + m * a.lddk + d0, v4);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// dK/dV, software-pipelined inside the wave (8 waves).  The triage builds of the plain kernel (OSUF_ATTN_DBG) showed its time
+// is the SUM of the MFMA time and of everything else (5.16 ms = 1.8 + 3.05 at N=4096): with 211 VGPRs there are two waves per
+// SIMD, both of one workgroup and in barrier lock-step, and inside a wave the stage is a strict chain
+// MFMA(S, dP) -> exp/VALU -> MFMA(dV, dK), so the matrix pipe idles during the VALU phase and vice versa.  Here iteration `it`
+// issues the S / dP products of stage it+1 (independent of everything else in the iteration) next to the exp/VALU work of
+// stage it, then the dV / dK products of stage it.  Two stages are live in LDS, so the ring has three slots and the global
+// prefetch runs two stages ahead.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void mqa_bwd_dkv_pipe_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // [3][Q 4K | dO 4K | lse 128 | delta 128]
+  constexpr int NW = 8, kStage = 4096 + 4096 + 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int nkb = (a.N + 32 * NW - 1) / (32 * NW);
+  const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;
+  const int b = (qid / nkb) * 8 + xcd;
+  const int kb = qid % nkb;
+  if (b >= a.B) return;
+  const int key = kb * (32 * NW) + wave * 32 + lr;
+  const bool kok = key < a.N;
+  const float c = a.scale * kLog2e;
+  const int nqb = (a.N + 31) >> 5;
+  const int niter = nqb * a.H;
+
+  bf16x8 kf[4], vf[4];
+  {
+    const long m = (long)b * a.N + key;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 z = {0u, 0u, 0u, 0u}, z2 = {0u, 0u, 0u, 0u};
+      if (kok) { z = *reinterpret_cast<const u32x4*>(a.k + m * a.ldk + 16 * ks + 8 * lh); z2 = *reinterpret_cast<const u32x4*>(a.v + m * a.ldv + 16 * ks + 8 * lh); }
+      kf[ks] = __builtin_bit_cast(bf16x8, z);
+      vf[ks] = __builtin_bit_cast(bf16x8, z2);
+    }
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+
+  // stage loader (512 threads, one 16-B chunk each): chunks 0..255 = Q tile, 256..511 = dO tile; threads 0..31 lse, 32..63 delta
+  const int lt = tid & 255, lrow = lt >> 3, lchunk = lt & 7;
+  const bf16_t* lsrc = tid < 256 ? a.q : a.dout;
+  const long lld = tid < 256 ? a.ldq : a.lddo;
+  const int lds_dst = (tid < 256 ? 0 : 4096) + tile_off(lrow, lchunk * 16);
+  u32x4 rt; float rs = 0.f;
+  int ih = 0, ipb = 0;                                            // (head, query block) of the next stage to load
+  auto load_stage = [&]() {
+    const int qrow = ipb * 32 + lrow;
+    u32x4 z = {0u, 0u, 0u, 0u};
+    rt = z;
+    if (qrow < a.N) rt = *reinterpret_cast<const u32x4*>(lsrc + ((long)b * a.N + qrow) * lld + ih * D + lchunk * 8);
+    if (tid < 64) {
+      const int qr = ipb * 32 + (tid & 31);
+      const long sidx = ((long)b * a.H + ih) * a.N + qr;
+      if (tid < 32) rs = qr < a.N ? a.lse2[sidx] : INFINITY;
+      else rs = qr < a.N ? a.delta[sidx] : 0.f;
+    }
+    if (++ih == a.H) { ih = 0; ++ipb; }
+  };
+  auto store_stage = [&](int slot) {
+    char* base = smem + slot * kStage;
+    *reinterpret_cast<u32x4*>(base + lds_dst) = rt;
+    if (tid < 64) reinterpret_cast<float*>(base + 8192)[tid] = rs;
+  };
+
+  const LaneOffs lo(lane);
+  auto qk = [&](int slot, f32x16& s, f32x16& dp) {                 // S[q][key] = Q K^T ; dP[q][key] = dO V^T
+    const char* qs = smem + slot * kStage;
+    const char* dos = qs + 4096;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(qs, lo, ks, 0), kf[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(dos, lo, ks, 0), vf[ks], dp, 0, 0, 0);
+    }
+  };
+  // one pipelined iteration: (sc, dpc) hold S / dP of stage `it` (slot), (sn, dpn) receive those of stage it+1 (slot_n).
+  // The issue order is written out by hand and pinned with sched_barrier fences (left alone, hipcc clusters the 16 exps first
+  // and the 16 MFMAs last): an MFMA pair of the next stage, then a quarter of this stage's exp / VALU work, ...; the dV / dK
+  // products of query rows 0-15 start as soon as their P / dS rows exist.
+#define OSUF_FENCE __builtin_amdgcn_sched_barrier(0)
+  auto iter = [&](int it, int slot, int slot_n, int slot_ld, f32x16& sc, f32x16& dpc, f32x16& sn, f32x16& dpn) {
+    const char* qs = smem + slot * kStage;
+    const char* dos = qs + 4096;
+    const float* ls = reinterpret_cast<const float*>(qs + 8192);
+    const char* qn = smem + slot_n * kStage;
+    const char* don = qn + 4096;
+    const bool more2 = it + 2 < niter;
+    if (more2) load_stage();
+    OSUF_FENCE;
+    bf16x8 fq[4], fo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { fq[ks] = lds_row_frag(qn, lo, ks, 0); fo[ks] = lds_row_frag(don, lo, ks, 0); }
+    f32x4 l4[4], d4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      l4[g] = *reinterpret_cast<const f32x4*>(ls + 8 * g + 4 * lh);
+      d4[g] = *reinterpret_cast<const f32x4*>(ls + 32 + 8 * g + 4 * lh);
+    }
+    f32x16 ds;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto valu_quarter = [&](int g) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        float p = fast_exp2(fmaf(sc[r], c, -l4[g][e]));
+        sc[r] = p;
+        ds[r] = p * (dpc[r] - d4[g][e]) * a.scale;
+      }
+    };
+    OSUF_FENCE;
+    sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[0], kf[0], zero16, 0, 0, 0);
+    dpn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[0], vf[0], zero16, 0, 0, 0);
+    valu_quarter(0);
+    OSUF_FENCE;
+    sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[1], kf[1], sn, 0, 0, 0);
+    dpn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[1], vf[1], dpn, 0, 0, 0);
+    valu_quarter(1);
+    OSUF_FENCE;
+    // transposed fragments of rows 0-15 + their P / dS operands while the next MFMA pair runs
+    sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[2], kf[2], sn, 0, 0, 0);
+    dpn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[2], vf[2], dpn, 0, 0, 0);
+    bf16x8 to0[2], tq0[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) { to0[dt] = lds_tr_frag(dos, lo, 0, dt); tq0[dt] = lds_tr_frag(qs, lo, 0, dt); }
+    const bf16x8 pf0 = acc_to_frag(sc, 0), df0 = acc_to_frag(ds, 0);
+    OSUF_FENCE;
+    sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[3], kf[3], sn, 0, 0, 0);
+    dpn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[3], vf[3], dpn, 0, 0, 0);
+    valu_quarter(2);
+    OSUF_FENCE;
+    // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]   (query rows 0-15)
+    dv[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to0[0], pf0, dv[0], 0, 0, 0);
+    dk[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq0[0], df0, dk[0], 0, 0, 0);
+    valu_quarter(3);
+    OSUF_FENCE;
+    dv[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to0[1], pf0, dv[1], 0, 0, 0);
+    dk[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq0[1], df0, dk[1], 0, 0, 0);
+    bf16x8 to1[2], tq1[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) { to1[dt] = lds_tr_frag(dos, lo, 16, dt); tq1[dt] = lds_tr_frag(qs, lo, 16, dt); }
+    const bf16x8 pf1 = acc_to_frag(sc, 1), df1 = acc_to_frag(ds, 1);
+    OSUF_FENCE;
+    dv[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to1[0], pf1, dv[0], 0, 0, 0);
+    dk[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq1[0], df1, dk[0], 0, 0, 0);
+    dv[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(to1[1], pf1, dv[1], 0, 0, 0);
+    dk[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq1[1], df1, dk[1], 0, 0, 0);
+    OSUF_FENCE;
+    if (more2) store_stage(slot_ld);
     __syncthreads();
+  };
+#undef OSUF_FENCE
+
+  load_stage(); store_stage(0);
+  if (niter > 1) { load_stage(); store_stage(1); }
+  __syncthreads();
+  f32x16 s0, dp0, s1, dp1;
+  qk(0, s0, dp0);
+  int slot = 0;                                                   // slot of stage `it`; the ring advances by one per iteration
+  for (int it = 0; it < niter; it += 2) {
+    const int sA = slot, sB = slot == 2 ? 0 : slot + 1, sC = sB == 2 ? 0 : sB + 1;
+    iter(it, sA, sB, sC, s0, dp0, s1, dp1);
+    if (it + 1 < niter) iter(it + 1, sB, sC, sA, s1, dp1, s0, dp0);
+    slot = sC;
   }
   if (kok) {
     const long m = (long)b * a.N + key;
@@ -644,7 +843,18 @@ extern "C" int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk
   a.dk = dk; a.dv = dv; a.lddk = lddk;
   const int b8 = (B + 7) / 8 * 8;
   if (attn_waves() == 4) hipLaunchKernelGGL(mqa_bwd_dkv_kernel<4>, dim3(((N + 127) / 128) * b8), dim3(256), 2 * (4096 + 4096 + 256), stream, a);
-  else hipLaunchKernelGGL(mqa_bwd_dkv_kernel<8>, dim3(((N + 255) / 256) * b8), dim3(512), 2 * (4096 + 4096 + 256), stream, a);
+  else {
+    static const int dbg = getenv("OSUF_ATTN_DBG") ? atoi(getenv("OSUF_ATTN_DBG")) : 0;
+    const dim3 grid(((N + 255) / 256) * b8);
+    const int lds = 2 * (4096 + 4096 + 256);
+    if (dbg == 1) hipLaunchKernelGGL((mqa_bwd_dkv_kernel<8, 1>), grid, dim3(512), lds, stream, a);
+    else if (dbg == 2) hipLaunchKernelGGL((mqa_bwd_dkv_kernel<8, 2>), grid, dim3(512), lds, stream, a);
+    else if (dbg == 3) hipLaunchKernelGGL((mqa_bwd_dkv_kernel<8, 3>), grid, dim3(512), lds, stream, a);
+    else if (dbg == 4) hipLaunchKernelGGL((mqa_bwd_dkv_kernel<8, 4>), grid, dim3(512), lds, stream, a);
+    else if (dbg == 5) hipLaunchKernelGGL((mqa_bwd_dkv_kernel<8, 5>), grid, dim3(512), lds, stream, a);
+    else if (getenv("OSUF_ATTN_NOPIPE")) hipLaunchKernelGGL(mqa_bwd_dkv_kernel<8>, grid, dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL(mqa_bwd_dkv_pipe_kernel, grid, dim3(512), 3 * (4096 + 4096 + 256), stream, a);
+  }
   return osuf_launch_status();
 }
 
