@@ -140,6 +140,10 @@ int osuf_pack_weight(const float* w, int O, int I, int k, int out_dtype, void* F
 int osuf_dora_effective(const float* W, const float* A, const float* B, const float* mag, int O, int IK, int r, float scaling,
                         float* Weff, float* g, hipStream_t stream);
 
+/* Measurement aid (no reference counterpart): sustained shader clock under an MFMA (mode 1) or VALU (mode 0) load.
+ * out[2*block] = shader cycles, out[2*block+1] = 100 MHz wall ticks. */
+int osuf_clock_probe(int blocks, int iters, int mode, long* out, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

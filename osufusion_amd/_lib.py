@@ -52,6 +52,7 @@ SIGNATURES = {
     "osuf_cast_f32_bf16": [P, P, L, P],
     "osuf_pack_weight": [P, I, I, I, I, P, L, L, P, L, L, I, P],
     "osuf_dora_effective": [P, P, P, P, I, I, I, F, P, P, P],
+    "osuf_clock_probe": [I, I, I, P, P],
 }
 
 _lib = None

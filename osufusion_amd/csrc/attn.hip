@@ -337,6 +337,155 @@ __global__ __launch_bounds__(NW * 64) void mqa_bwd_dq_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// dQ, software-pipelined inside the wave (8 waves; same finding as for dK/dV below: with one workgroup per CU the plain loop's
+// MFMA time and exp/VALU time add up instead of overlapping).  Iteration j issues, interleaved by hand and pinned with
+// sched_barrier fences: the S^T / dP^T products of key tile j+1 (16 MFMAs), the exp / dS arithmetic of tile j (32 elements per
+// lane, in 8 slices), and the dQ products of tile j-1 (8 MFMAs, from the bf16 dS fragments carried over).  Three key tiles are
+// live in LDS and a fourth is being filled: 4-slot ring of (K 8 KiB | V 8 KiB).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void mqa_bwd_dq_pipe_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // [4][K 8K | V 8K]
+  constexpr int NW = 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y;
+  const int nqb = (a.N + 31) >> 5;
+  const int vb = blockIdx.x * NW + wave;
+  const bool active = vb < nqb * a.H;
+  const int h = active ? vb % a.H : 0, pb = active ? vb / a.H : 0;
+  const int qrow = pb * 32 + lr;
+  const bool qok = active && qrow < a.N;
+  const float c = a.scale * kLog2e;
+
+  bf16x8 qf[4], dof[4];
+  {
+    const bf16_t* qp = a.q + ((long)b * a.N + qrow) * a.ldq + h * D;
+    const bf16_t* dp = a.dout + ((long)b * a.N + qrow) * a.lddo + h * D;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 z = {0u, 0u, 0u, 0u}, z2 = {0u, 0u, 0u, 0u};
+      if (qok) { z = *reinterpret_cast<const u32x4*>(qp + 16 * ks + 8 * lh); z2 = *reinterpret_cast<const u32x4*>(dp + 16 * ks + 8 * lh); }
+      qf[ks] = __builtin_bit_cast(bf16x8, z);
+      dof[ks] = __builtin_bit_cast(bf16x8, z2);
+    }
+  }
+  const long sidx = ((long)b * a.H + h) * a.N + qrow;
+  const float L2 = qok ? a.lse2[sidx] : INFINITY;
+  const float dl = qok ? a.delta[sidx] : 0.f;
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const LaneOffs lo(lane);
+  const int ntiles = (a.N + 63) >> 6;
+  KVStage<NW * 64> st;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto tile_k = [&](int slot) { return smem + slot * 16384; };
+
+  // S^T / dP^T of one tile, unpipelined (prologue only)
+  auto qk_plain = [&](int slot, f32x16 (&s)[2], f32x16 (&dp)[2]) {
+    const char* ks_ = tile_k(slot);
+    const char* vs_ = ks_ + 8192;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      s[kt] = zero16; dp[kt] = zero16;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(ks_, lo, ks, kt), qf[ks], s[kt], 0, 0, 0);
+        dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(vs_, lo, ks, kt), dof[ks], dp[kt], 0, 0, 0);
+      }
+    }
+  };
+  // dQ products of one tile from its bf16 dS fragments, unpipelined (epilogue only)
+  auto dq_plain = [&](int slot, const bf16x8 (&df)[4]) {
+    const char* ks_ = tile_k(slot);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(ks_, lo, (s4 >> 1) * 32 + (s4 & 1) * 16, dt), df[s4], acc[dt], 0, 0, 0);
+  };
+
+#define OSUF_FENCE __builtin_amdgcn_sched_barrier(0)
+  // iteration j: (sc, dpc) = S^T / dP^T of tile j (slot_c irrelevant: registers only); tile j+1 in slot_n; tile j-1 in slot_p with
+  // its dS fragments in dfp; the tile loaded two ahead goes to slot_ld.  On return dfp holds tile j's fragments.
+  auto iter = [&](int j, int slot_p, int slot_n, int slot_ld, f32x16 (&sc)[2], f32x16 (&dpc)[2], f32x16 (&sn)[2], f32x16 (&dpn)[2],
+                  bf16x8 (&dfp)[4]) {
+    const char* kn = tile_k(slot_n);
+    const char* vn = kn + 8192;
+    const char* kp = tile_k(slot_p);
+    const bool more2 = j + 2 < ntiles;
+    if (more2) st.load(a, b, (j + 2) * 64, tid);
+    OSUF_FENCE;
+    // 8 steps (kt = i>>2, ks = i&3): 3 MFMAs on the fragments fetched during the previous step, then the fetch for the next
+    // step, then a 4-element slice of the exp / dS arithmetic (which hides that fetch's LDS latency)
+    bf16x8 fk[2], fv[2], tk[2];
+    auto fetch = [&](int i, int set) {
+      const int kt = i >> 2, ks = i & 3, s4 = i >> 1;
+      fk[set] = lds_row_frag(kn, lo, ks, kt);
+      fv[set] = lds_row_frag(vn, lo, ks, kt);
+      tk[set] = lds_tr_frag(kp, lo, (s4 >> 1) * 32 + (s4 & 1) * 16, i & 1);
+    };
+    fetch(0, 0);
+    OSUF_FENCE;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kt = i >> 2, ks = i & 3, set = i & 1;
+      sn[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[set], qf[ks], ks == 0 ? zero16 : sn[kt], 0, 0, 0);
+      dpn[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv[set], dof[ks], ks == 0 ? zero16 : dpn[kt], 0, 0, 0);
+      acc[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tk[set], dfp[i >> 1], acc[i & 1], 0, 0, 0);
+      if (i < 7) fetch(i + 1, set ^ 1);
+      // dS^T = P^T * (dP^T - delta) * scale for 4 of this lane's 32 (key, query) elements of tile j
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * ks + e;
+        float p = fast_exp2(fmaf(sc[kt][r], c, -L2));
+        sc[kt][r] = p * (dpc[kt][r] - dl) * a.scale;
+        asm volatile("" : "+v"(sc[kt][r]));            // keep the slice HERE (its only consumer is the conversion at the end of the
+      }                                                  // iteration, and code sinking would otherwise move all 32 exps behind the MFMAs)
+      OSUF_FENCE;
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) dfp[s4] = acc_to_frag(sc[s4 >> 1], s4 & 1);
+    OSUF_FENCE;
+    if (more2) st.store(tile_k(slot_ld), tile_k(slot_ld) + 8192, tid);
+    __syncthreads();
+  };
+#undef OSUF_FENCE
+
+  st.load(a, b, 0, tid);
+  st.store(tile_k(0), tile_k(0) + 8192, tid);
+  if (ntiles > 1) { st.load(a, b, 64, tid); st.store(tile_k(1), tile_k(1) + 8192, tid); }
+  __syncthreads();
+  f32x16 s0[2], dp0[2], s1[2], dp1[2];
+  bf16x8 dfp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dfp[i] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});   // "tile -1": adds zero
+  qk_plain(0, s0, dp0);
+  // slots: tile t lives in slot t & 3; on the first iteration the "previous" tile is a zero fragment times whatever slot 3 holds
+  // -- uninitialised LDS could be NaN/Inf bits, so clear slot 3's K half once
+  for (int i = tid; i < 8192 / 16; i += NW * 64) reinterpret_cast<u32x4*>(tile_k(3))[i] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  for (int j = 0; j < ntiles; j += 2) {
+    iter(j, (j + 3) & 3, (j + 1) & 3, (j + 2) & 3, s0, dp0, s1, dp1, dfp);
+    if (j + 1 < ntiles) iter(j + 1, j & 3, (j + 2) & 3, (j + 3) & 3, s1, dp1, s0, dp0, dfp);
+  }
+  dq_plain((ntiles - 1) & 3, dfp);
+  if (qok) {
+    const long m = (long)b * a.N + qrow;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v4[4] = {acc[dt][4 * g], acc[dt][4 * g + 1], acc[dt][4 * g + 2], acc[dt][4 * g + 3]};
+        store4(a.dq + m * a.lddq + h * D + dt * 32 + 8 * g + 4 * lh, v4);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // backward, dK/dV: key-stationary.  A wave owns 32 keys; the workgroup (8 waves = 256 keys) sweeps every
 // (head, 32-query block) pair, staging Q / dO / lse / delta of the pair in LDS for all waves.
 // ------------------------------------------------------------------------------------------------------
@@ -828,7 +977,13 @@ extern "C" int osuf_mqa_bwd_dq(const void* q, long ldq, const void* k, long ldk,
   a.dq = dq; a.lddq = lddq;
   const int nvb = ((N + 31) / 32) * H;
   if (attn_waves() == 4) hipLaunchKernelGGL(mqa_bwd_dq_kernel<4>, dim3((nvb + 3) / 4, B), dim3(256), 32768, stream, a);
-  else hipLaunchKernelGGL(mqa_bwd_dq_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768, stream, a);
+  // the pipelined kernel (2 waves/SIMD, 256 VGPRs) wins once the key loop is long: +4.5 % at N=4096, even at 2048, -3 % at <= 1024
+  else if (N < 3072 || getenv("OSUF_ATTN_NOPIPE")) hipLaunchKernelGGL(mqa_bwd_dq_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768, stream, a);
+  else {
+    static bool once = ((void)hipFuncSetAttribute((const void*)mqa_bwd_dq_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), true);
+    (void)once;
+    hipLaunchKernelGGL(mqa_bwd_dq_pipe_kernel, dim3((nvb + 7) / 8, B), dim3(512), 65536, stream, a);
+  }
   return osuf_launch_status();
 }
 

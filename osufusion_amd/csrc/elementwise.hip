@@ -394,4 +394,43 @@ extern "C" int osuf_dora_effective(const float* W, const float* A, const float* 
   return osuf_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Clock probe (tools/clock_probe.py): every wave runs `iters` x 8 independent v_mfma_f32_32x32x16_bf16 back to back (mode 1) or
+// the same number of v_fma_f32 (mode 0) and reports shader-clock cycles (s_memtime) and 100 MHz wall ticks (s_memrealtime):
+// the frequency the chip actually sustains under a matrix-core load, i.e. what "fraction of the 2.4 GHz peak" can mean.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void clock_probe_kernel(int iters, int mode, long* out) {
+  typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+  f32x16 acc[8];
+  for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  bf8 av, bv;
+  for (int i = 0; i < 8; ++i) { av[i] = (__bf16)(0.001f * (threadIdx.x + i)); bv[i] = (__bf16)(0.002f * (threadIdx.x + 2 * i)); }
+  float f = threadIdx.x * 1e-3f;
+  const long c0 = __builtin_readcyclecounter();
+  const long t0 = wall_clock64();
+  if (mode == 1) {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);
+    }
+  } else {
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) f = fmaf(f, 1.0001f, 0.5f);
+    }
+  }
+  const long c1 = __builtin_readcyclecounter();
+  const long t1 = wall_clock64();
+  float sum = f;
+  for (int i = 0; i < 8; ++i) sum += acc[i][0];
+  if (threadIdx.x == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = t1 - t0; }
+  if (sum == 123.456f) out[0] = 0;
+}
+
+extern "C" int osuf_clock_probe(int blocks, int iters, int mode, long* out, hipStream_t stream) {
+  if (blocks <= 0 || iters <= 0 || !out) return OSUF_EINVAL;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, stream, iters, mode, out);
+  return osuf_launch_status();
+}
+
 extern "C" int osuf_version(void) { return 1; }
