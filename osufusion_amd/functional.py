@@ -311,7 +311,18 @@ class BlockFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         tg, tb = grad_target(gamma), grad_target(beta)
         direct_norm = tg is not None and tb is not None
-        dy, dgamma, dbeta, dss = ops.gn_bwd(_rc(dh), y, mr, gamma, beta, ss, L, tg if direct_norm else None, tb if direct_norm else None)
+        # conv-bias gradient (= column sums of dy) comes out of the GroupNorm backward in closed form: no extra pass over dy
+        bias = ctx.bias_ref
+        db = None
+        tbias = None
+        if need[2] and bias is not None:
+            tbias = grad_target(bias)
+            if tbias is None:
+                db = tbias = torch.zeros(bias.shape, dtype=torch.float32, device=dh.device)
+        dy, dgamma, dbeta, dss = ops.gn_bwd(_rc(dh), y, mr, gamma, beta, ss, L, tg if direct_norm else None, tb if direct_norm else None,
+                                            tbias)
+        if tbias is not None and db is None:
+            grad_done(bias)
         if direct_norm:
             grad_done(gamma); grad_done(beta)
             dgamma = dbeta = None
@@ -321,7 +332,6 @@ class BlockFn(torch.autograd.Function):
             dx = conv_dgrad(dy, ad.effective()[0], ctx.cache, "same", L, vp=("dora", *ad.params)) if ad is not None \
                 else conv_dgrad(dy, w, ctx.cache, "same", L)
         dw = conv_wgrad(dy, x, w, "same") if need[1] else None
-        db = _bias_grad(dy, ctx.bias_ref) if need[2] else None
         da = dlb = dm = None
         if ad is not None and (need[8] or need[9] or need[10]):
             da, dlb, dm = adapter_grads(ad, dy, x, y, ctx.bias_ref, "same", ctx.cache)
