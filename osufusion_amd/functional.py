@@ -338,18 +338,30 @@ class BlockFn(torch.autograd.Function):
         return dx, dw, db, dgamma if need[3] else None, dbeta if need[4] else None, dss, None, None, da, dlb, dm
 
 
+class GateLink:
+    """Per-forward hand-off between the two Functions that both differentiate the block output h (gate * h + res, and the
+    GlobalContext pooling of h).  GateRes*Fn.backward runs first (it is downstream): instead of materialising dout * gate and
+    letting autograd add the pooling path's gradient to it later (one elementwise kernel + one add over (B, L, C) per block), it
+    parks (dout, gate) here and returns no gradient for h; GCAPoolFn.backward then emits the complete
+    dh = dout * gate + p * dpooled + dlogit * wk from the one fused kernel."""
+    __slots__ = ("dout", "gate")
+
+    def __init__(self) -> None:
+        self.dout = self.gate = None
+
+
 class GCAPoolFn(torch.autograd.Function):
     """GlobalContext pooling: pooled[b,c] = sum_n softmax_n(h.wk + bk)[n] * h[b,n,c]   (residual.py:29-31) -> fp32 (B,C)."""
 
     @staticmethod
-    def forward(ctx, h, wk, bk):
+    def forward(ctx, h, wk, bk, link=None):
         B, L, C = h.shape
         wkv = wk.reshape(-1).contiguous()
         p = ops.rowdot(h, wkv, bk.reshape(-1), L)
         ops.softmax_rows_(p, B, L)
         pooled = ops.wcolsum(h, None, p, B, L)
         ctx.save_for_backward(h, wkv, p, pooled)
-        ctx.wshape = wk.shape
+        ctx.wshape, ctx.link = wk.shape, link
         return pooled
 
     @staticmethod
@@ -358,22 +370,35 @@ class GCAPoolFn(torch.autograd.Function):
         B, L, C = h.shape
         dpooled = dpooled.contiguous().float()
         sdot = (pooled * dpooled).sum(1).contiguous()
-        zero_gate = torch.zeros((B, C), dtype=torch.float32, device=h.device)
-        # dh = p*dpooled + dlogit*wk  (the `dout*gate` term of the fused kernel is disabled with a zero gate)
-        dh, dlogit = ops.gca_bwd_apply(h, h, p, zero_gate, dpooled, sdot, wkv, L)
+        link = ctx.link
+        if link is not None and link.dout is not None:
+            dout, gate = link.dout, link.gate
+            link.dout = link.gate = None
+        else:                                              # stand-alone GlobalContext: no dout * gate term
+            dout, gate = h, torch.zeros((B, C), dtype=torch.float32, device=h.device)
+        dh, dlogit = ops.gca_bwd_apply(dout, h, p, gate, dpooled, sdot, wkv, L)
         dwk = ops.wcolsum(h, None, dlogit, B, L).sum(0).reshape(ctx.wshape) if ctx.needs_input_grad[1] else None   # frozen base: skip the pass
         dbk = dlogit.sum().reshape(1) if ctx.needs_input_grad[2] else None
-        return dh, dwk, dbk
+        return dh, dwk, dbk, None
+
+
+def _gate_dh(link, dout, gate, L):
+    """Gradient of gate * h w.r.t. h: deferred to GCAPoolFn.backward when the two are linked (see GateLink)."""
+    if link is not None:
+        link.dout, link.gate = dout, gate
+        return None
+    return ops.gate_residual(dout, gate, None, L)
 
 
 class GateResFn(torch.autograd.Function):
     """out = h * gate + res   (residual.py:135-137, identity res_conv).  gate fp32 (B, C)."""
 
     @staticmethod
-    def forward(ctx, h, gate, res):
+    def forward(ctx, h, gate, res, link=None):
         L = h.shape[1]
         gate = gate.contiguous()
         ctx.save_for_backward(h, gate)
+        ctx.link = link
         return ops.gate_residual(h, gate, res, L)
 
     @staticmethod
@@ -382,18 +407,17 @@ class GateResFn(torch.autograd.Function):
         B, L, C = h.shape
         dout = _rc(dout)
         dgate = ops.wcolsum(dout, h, None, B, L)
-        dh = ops.gate_residual(dout, gate, None, L)                 # dout * gate
-        return dh, dgate, dout
+        return _gate_dh(ctx.link, dout, gate, L), dgate, dout, None
 
 
 class GateResConvFn(torch.autograd.Function):
     """out = h * gate + res_conv(x)  (residual.py:135-137, 1x1 res_conv): the gate-multiply rides the GEMM epilogue."""
 
     @staticmethod
-    def forward(ctx, h, gate, x, w, bias, cache):
+    def forward(ctx, h, gate, x, w, bias, cache, link=None):
         gate = gate.contiguous()
         ctx.save_for_backward(h, gate, x, w)
-        ctx.cache, ctx.bias_ref = cache, bias
+        ctx.cache, ctx.bias_ref, ctx.link = cache, bias, link
         return conv_forward(x, w, bias, cache, "same", None, residual=h, rscale=gate)
 
     @staticmethod
@@ -402,11 +426,11 @@ class GateResConvFn(torch.autograd.Function):
         B, L, C = h.shape
         dout = _rc(dout)
         dgate = ops.wcolsum(dout, h, None, B, L)
-        dh = ops.gate_residual(dout, gate, None, L)
+        dh = _gate_dh(ctx.link, dout, gate, L)
         dx = conv_dgrad(dout, w, ctx.cache, "same", L)
         dw = conv_wgrad(dout, x, w, "same") if ctx.needs_input_grad[3] else None
         db = _bias_grad(dout, ctx.bias_ref) if ctx.needs_input_grad[4] else None
-        return dh, dgate, dx, dw, db, None
+        return dh, dgate, dx, dw, db, None, None
 
 
 class FeedForwardFn(torch.autograd.Function):

@@ -28,9 +28,9 @@ class GlobalContext(nn.Module):
         )
         self._c0, self._c2 = Fn.PackCache(), Fn.PackCache()
 
-    def gate_from_rows(self, h: torch.Tensor) -> torch.Tensor:
-        """rows (B, L, C) -> gate fp32 (B, C_out)."""
-        pooled = Fn.GCAPoolFn.apply(h, self.to_k.weight, self.to_k.bias)
+    def gate_from_rows(self, h: torch.Tensor, link=None) -> torch.Tensor:
+        """rows (B, L, C) -> gate fp32 (B, C_out).  link: functional.GateLink shared with the gate * h consumer."""
+        pooled = Fn.GCAPoolFn.apply(h, self.to_k.weight, self.to_k.bias, link)
         l0, l2 = self.layers[0], self.layers[2]
         z = rt.small_linear(pooled, l0.weight, l0.bias, self._c0, "l0")
         z = rt.small_linear(F.silu(z), l2.weight, l2.bias, self._c2, "l2")
@@ -98,10 +98,11 @@ class ResidualBlock(nn.Module):
             ss = rt.small_linear(F.silu(emb), lin.weight, lin.bias, self._cm, "mlp")     # (B, 2C): scale | shift
         h = self.block1.forward_rows(x, ss)
         h = self.block2.forward_rows(h, None)
-        gate = self.se.gate_from_rows(h)
+        link = Fn.GateLink() if torch.is_grad_enabled() and h.requires_grad else None
+        gate = self.se.gate_from_rows(h, link)
         if isinstance(self.res_conv, nn.Identity):
-            return Fn.GateResFn.apply(h, gate, x)
-        return Fn.GateResConvFn.apply(h, gate, x, self.res_conv.weight, self.res_conv.bias, self._cr)
+            return Fn.GateResFn.apply(h, gate, x, link)
+        return Fn.GateResConvFn.apply(h, gate, x, self.res_conv.weight, self.res_conv.bias, self._cr, link)
 
     def forward(self, x: torch.Tensor, t: Optional[torch.Tensor] = None, c: Optional[torch.Tensor] = None) -> torch.Tensor:
         rows = rt.to_rows(x, rt.compute_dtype(self.block1.proj.weight.dtype))
