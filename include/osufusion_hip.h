@@ -141,6 +141,19 @@ int osuf_pack_weight(const float* w, int O, int I, int k, int out_dtype, void* F
 int osuf_dora_effective(const float* W, const float* A, const float* B, const float* mag, int O, int IK, int r, float scaling,
                         float* Weff, float* g, hipStream_t stream);
 
+/* ---- embedding-sized linears (skinny.hip)    replaces: time_mlp / cond_mlp (modules/unet.py:356-367), the FiLM projection
+ *      (residual.py:104-111,126-133) and GlobalContext's squeeze-excite MLP (residual.py:20-26,33-37) -- nn.Linear / 1x1 Conv1d on
+ *      (B, features) rows.  fp32 in / out, W (N, K) fp32 master read in place; mode OSUF_DT_BF16 rounds both operands to bf16
+ *      (autocast semantics), OSUF_DT_F32 is exact f32.  in_act: 0 none, 1 SiLU applied to x; out_act: 0 none, 2 sigmoid.
+ *        fwd: y = out_act(in_act(x) W^T + b)
+ *        bwd: dz = dy * out_act'(y); dx = (dz W) * in_act'(x) [dx may be NULL]; dW (+)= dz^T in_act(x), db += colsum(dz)
+ *             [dW / db may be NULL; db needs dW] ---- */
+int osuf_skinny_fwd(int mode, const float* x, long ldx, const float* W, const float* bias, float* y, long ldy, int M, int N, int K,
+                    int in_act, int out_act, hipStream_t stream);
+int osuf_skinny_bwd(int mode, const float* dy, long lddy, const float* y, long ldy, const float* x, long ldx, const float* W,
+                    float* dx, long lddx, float* dW, float* db, int M, int N, int K, int in_act, int out_act, int accumulate,
+                    hipStream_t stream);
+
 /* Measurement aid (no reference counterpart): sustained shader clock under an MFMA (mode 1) or VALU (mode 0) load.
  * out[2*block] = shader cycles, out[2*block+1] = 100 MHz wall ticks. */
 int osuf_clock_probe(int blocks, int iters, int mode, long* out, hipStream_t stream);

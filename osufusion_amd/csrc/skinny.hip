@@ -1,0 +1,236 @@
+// Embedding-sized linears (M = batch rows, a few dozen): time / condition MLPs and the GlobalContext squeeze-excite MLP
+// (reference: unet.py:356-367, residual.py:20-26,33-37).  These are weight-streaming problems -- 2*M*N*K FLOPs against N*K*4 B of
+// fp32 master weights read ONCE -- that went through the conv GEMM path at 12 launches per linear and direction (casts, pads,
+// two weight packs, 128-row tiles for 32 rows, separate bias / activation / column-sum kernels).  Here: fp32 in, fp32 out, the
+// fp32 master weight read in place, input SiLU / output sigmoid / bias and their derivatives fused, three kernels in total:
+//   skinny_fwd : y = out_act( in_act(x) W^T + b )                   one workgroup per 32 output columns, K split over 4 waves
+//   skinny_dx  : dx = ( (dy * out_act'(y)) W ) * in_act'(x)          one workgroup per 32 input columns, N split over 4 waves
+//   skinny_dw  : dW += (dy * out_act')^T in_act(x) ;  db += column sums      one wave per 32x32 tile of dW
+// Arithmetic follows the compute mode like every other linear: MODE 1 rounds both operands to bf16 and uses
+// v_mfma_f32_32x32x16_bf16 (what torch autocast does to nn.Linear / 1x1 Conv1d); MODE 0 uses v_mfma_f32_32x32x2f32 (exact f32).
+#include "common.hpp"
+
+#define SK_ACT_NONE 0
+#define SK_ACT_SILU 1
+#define SK_ACT_SIGMOID 2
+
+// 8 consecutive floats row[k .. k+8) with zero fill past K (and for a null row)
+__device__ __forceinline__ void sk_load8(const float* row, int k, int K, float (&v)[8]) {
+  if (row != nullptr && k + 8 <= K && ((reinterpret_cast<uintptr_t>(row + k) & 15) == 0)) {
+    load8(row + k, v);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (row != nullptr && k + j < K) ? row[k + j] : 0.f;
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ void sk_mma(const float (&a)[8], const float (&b)[8], f32x16& acc) {
+  if constexpr (MODE == 1) {
+    bf16x8 fa, fb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { fa[j] = (__bf16)a[j]; fb[j] = (__bf16)b[j]; }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+  }
+}
+
+// cross-wave sum of the four partial 32x32 accumulators: red[wave][row*32 + col]; returns after the barrier
+__device__ __forceinline__ void sk_reduce_store(float* red, int wave, int lane, const f32x16& acc) {
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = acc[r];
+  __syncthreads();
+}
+
+// y[m][n] = out_act( sum_k in_act(x[m][k]) W[n][k] + b[n] )
+template <int MODE>
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ W, const float* __restrict__ bias,
+                                                         float* __restrict__ y, long ldy, int M, int N, int K, int in_act, int out_act) {
+  __shared__ float red[4 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * 32;
+  const float* wrow = (n0 + lr < N) ? W + (long)(n0 + lr) * K : nullptr;
+  for (int m0 = 0; m0 < M; m0 += 32) {
+    const float* xrow = (m0 + lr < M) ? x + (long)(m0 + lr) * ldx : nullptr;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kb = 16 * wave; kb < K; kb += 64) {
+      float a[8], b[8];
+      sk_load8(xrow, kb + 8 * lh, K, a);
+      sk_load8(wrow, kb + 8 * lh, K, b);
+      if (in_act == SK_ACT_SILU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = silu_f(a[j]);
+      }
+      sk_mma<MODE>(a, b, acc);
+    }
+    sk_reduce_store(red, wave, lane, acc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 5, col = idx & 31;
+      const int m = m0 + row, n = n0 + col;
+      if (m < M && n < N) {
+        float v = red[idx] + red[1024 + idx] + red[2048 + idx] + red[3072 + idx] + (bias ? bias[n] : 0.f);
+        if (out_act == SK_ACT_SIGMOID) v = sigmoid_f(v);
+        else if (out_act == SK_ACT_SILU) v = silu_f(v);
+        y[(long)m * ldy + n] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ float sk_dact_from_out(int out_act, float yv) {      // derivative expressed through the OUTPUT
+  return out_act == SK_ACT_SIGMOID ? yv * (1.f - yv) : 1.f;
+}
+
+// dx[m][k] += in_act'(x[m][k]) * sum_{n in this block's slice} dz[m][n] W[n][k],   dz = dy * out_act'(y)
+// grid (K/32, nsplit): a 32-column strip of W is a strided read (128 B per row), so the N range is cut into `nsplit` slices to
+// put >= 256 workgroups on the chip; slices combine by fp32 atomics into a zeroed dx (the in_act' factor distributes over them).
+template <int MODE>
+__global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ y, long ldy,
+                                                        const float* __restrict__ W, const float* __restrict__ x, long ldx, float* __restrict__ dx,
+                                                        long lddx, int M, int N, int K, int in_act, int out_act, int n_per_split) {
+  __shared__ float red[4 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int k0 = blockIdx.x * 32;
+  const int n_begin = blockIdx.y * n_per_split, n_end = min(N, n_begin + n_per_split);
+  const bool atomic = gridDim.y > 1;
+  for (int m0 = 0; m0 < M; m0 += 32) {
+    const bool mok = m0 + lr < M;
+    const float* dyrow = mok ? dy + (long)(m0 + lr) * lddy : nullptr;
+    const float* yrow = (mok && out_act != SK_ACT_NONE) ? y + (long)(m0 + lr) * ldy : nullptr;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 2
+    for (int nb = n_begin + 16 * wave; nb < n_end; nb += 64) {
+      float a[8], b[8];
+      sk_load8(dyrow, nb + 8 * lh, n_end, a);
+      if (out_act != SK_ACT_NONE) {
+        float yv[8];
+        sk_load8(yrow, nb + 8 * lh, n_end, yv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] *= sk_dact_from_out(out_act, yv[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int n = nb + 8 * lh + j;
+        b[j] = (n < n_end && k0 + lr < K) ? W[(long)n * K + k0 + lr] : 0.f;
+      }
+      sk_mma<MODE>(a, b, acc);
+    }
+    sk_reduce_store(red, wave, lane, acc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 5, col = idx & 31;
+      const int m = m0 + row, k = k0 + col;
+      if (m < M && k < K) {
+        float v = red[idx] + red[1024 + idx] + red[2048 + idx] + red[3072 + idx];
+        if (in_act == SK_ACT_SILU) v *= silu_grad_f(x[(long)m * ldx + k]);
+        if (atomic) atomic_add_f32(dx + (long)m * lddx + k, v);
+        else dx[(long)m * lddx + k] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// dW[n][k] (+)= sum_m dz[m][n] in_act(x[m][k]) ;  db[n] += sum_m dz[m][n]      one wave per 32x32 tile, 4 tiles per workgroup
+template <int MODE>
+__global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ y, long ldy,
+                                                        const float* __restrict__ x, long ldx, float* __restrict__ dW, float* __restrict__ db,
+                                                        int M, int N, int K, int in_act, int out_act, int accumulate) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+  const int ktiles = (K + 31) >> 5, ntiles = (N + 31) >> 5;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= ktiles * ntiles) return;
+  const int n0 = (tile / ktiles) * 32, k0 = (tile % ktiles) * 32;
+  const int n = n0 + lr, k = k0 + lr;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  for (int mb = 0; mb < M; mb += 16) {
+    float a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = mb + 8 * lh + j;
+      float dz = 0.f, xv = 0.f;
+      if (m < M) {
+        if (n < N) {
+          dz = dy[(long)m * lddy + n];
+          if (out_act != SK_ACT_NONE) dz *= sk_dact_from_out(out_act, y[(long)m * ldy + n]);
+        }
+        if (k < K) { xv = x[(long)m * ldx + k]; if (in_act == SK_ACT_SILU) xv = silu_f(xv); }
+      }
+      a[j] = dz; b[j] = xv;
+      bsum += dz;
+    }
+    sk_mma<MODE>(a, b, acc);
+  }
+  if (db != nullptr && k0 == 0) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lh == 0 && n < N) db[n] += bsum;                     // the k0 == 0 tile is the only writer of db[n0 .. n0+32)
+  }
+  if (k < K) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int nn = n0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (nn < N) {
+        float* dst = dW + (long)nn * K + k;
+        *dst = accumulate ? *dst + acc[r] : acc[r];
+      }
+    }
+  }
+}
+
+static bool sk_bad(int M, int N, int K, int in_act, int out_act) {
+  return M <= 0 || N <= 0 || K <= 0 || (in_act != SK_ACT_NONE && in_act != SK_ACT_SILU) ||
+         (out_act != SK_ACT_NONE && out_act != SK_ACT_SIGMOID);
+}
+
+extern "C" int osuf_skinny_fwd(int mode, const float* x, long ldx, const float* W, const float* bias, float* y, long ldy, int M, int N, int K,
+                               int in_act, int out_act, hipStream_t stream) {
+  if (!x || !W || !y || sk_bad(M, N, K, in_act, out_act)) return OSUF_EINVAL;
+  const dim3 grid((N + 31) / 32);
+  if (mode == OSUF_DT_BF16) hipLaunchKernelGGL(skinny_fwd_kernel<1>, grid, dim3(256), 0, stream, x, ldx, W, bias, y, ldy, M, N, K, in_act, out_act);
+  else hipLaunchKernelGGL(skinny_fwd_kernel<0>, grid, dim3(256), 0, stream, x, ldx, W, bias, y, ldy, M, N, K, in_act, out_act);
+  return osuf_launch_status();
+}
+
+/* dx may be NULL (input needs no gradient); dW / db may be NULL (frozen parameters); accumulate: dW += instead of = (db is always +=) */
+extern "C" int osuf_skinny_bwd(int mode, const float* dy, long lddy, const float* y, long ldy, const float* x, long ldx, const float* W,
+                               float* dx, long lddx, float* dW, float* db, int M, int N, int K, int in_act, int out_act, int accumulate,
+                               hipStream_t stream) {
+  if (!dy || !x || !W || sk_bad(M, N, K, in_act, out_act) || (out_act != SK_ACT_NONE && !y)) return OSUF_EINVAL;
+  if (dx) {
+    const int ktiles = (K + 31) / 32;
+    int nsplit = (256 + ktiles - 1) / ktiles;                 // about one workgroup per CU
+    const int max_split = (N + 127) / 128;                    // but at least 128 rows of W per slice
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    int nps = (N + nsplit - 1) / nsplit;
+    nps = (nps + 63) / 64 * 64;                                // whole 64-row steps (4 waves x 16) and 8-float alignment of the slices
+    nsplit = (N + nps - 1) / nps;
+    if (nsplit > 1) (void)hipMemsetAsync(dx, 0, (size_t)M * lddx * sizeof(float), stream);
+    const dim3 grid(ktiles, nsplit);
+    if (mode == OSUF_DT_BF16)
+      hipLaunchKernelGGL(skinny_dx_kernel<1>, grid, dim3(256), 0, stream, dy, lddy, y, ldy, W, x, ldx, dx, lddx, M, N, K, in_act, out_act, nps);
+    else
+      hipLaunchKernelGGL(skinny_dx_kernel<0>, grid, dim3(256), 0, stream, dy, lddy, y, ldy, W, x, ldx, dx, lddx, M, N, K, in_act, out_act, nps);
+  }
+  if (dW) {
+    const int tiles = ((K + 31) / 32) * ((N + 31) / 32);
+    const dim3 grid((tiles + 3) / 4);
+    if (mode == OSUF_DT_BF16)
+      hipLaunchKernelGGL(skinny_dw_kernel<1>, grid, dim3(256), 0, stream, dy, lddy, y, ldy, x, ldx, dW, db, M, N, K, in_act, out_act, accumulate);
+    else
+      hipLaunchKernelGGL(skinny_dw_kernel<0>, grid, dim3(256), 0, stream, dy, lddy, y, ldy, x, ldx, dW, db, M, N, K, in_act, out_act, accumulate);
+  }
+  return osuf_launch_status();
+}

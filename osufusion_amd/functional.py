@@ -281,6 +281,45 @@ class AdaptedConvFn(torch.autograd.Function):
         return dx, db, None, None, None, da, dlb, dm
 
 
+class SkinnyLinearFn(torch.autograd.Function):
+    """y = out_act(in_act(x) W^T + b) on (B, features) fp32 rows: the embedding-sized nn.Linear / 1x1 Conv1d layers
+    (unet.py:356-367, residual.py:20-26,104-111), one kernel forward, two backward, master weights read in place."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, mode_dtype, in_act, out_act):
+        x = x.contiguous()
+        y = ops.skinny_fwd(x, w, bias, mode_dtype, in_act, out_act)
+        ctx.save_for_backward(x, w, y if out_act else x)
+        ctx.cfg, ctx.bias_ref = (mode_dtype, in_act, out_act), bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        mode_dtype, in_act, out_act = ctx.cfg
+        need = ctx.needs_input_grad
+        bias = ctx.bias_ref
+        dy = dy.contiguous().float()
+        dw = db = None
+        tw = tb = None
+        direct = False
+        if need[1]:
+            tw = grad_target(w)
+            direct = tw is not None
+            if not direct:
+                dw = tw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
+            if bias is not None and need[2]:
+                tb = grad_target(bias) if direct else None
+                if tb is None:
+                    db = tb = torch.zeros(bias.shape, dtype=torch.float32, device=w.device)
+        dx = ops.skinny_bwd(dy, y if out_act else None, x, w, mode_dtype, in_act, out_act, need[0], tw, tb, direct)
+        if direct:
+            grad_done(w)
+            if tb is not None and db is None:
+                grad_done(bias)
+        return dx, dw, db, None, None, None
+
+
 class BlockFn(torch.autograd.Function):
     """conv k3 -> GroupNorm(1,C) -> FiLM -> SiLU   (residual.py:75-84).  ss: fp32 (B, 2C) = (scale | shift) or None.
     adapter (+ its parameters la, lb, lm as autograd inputs): LoRA / DoRA on the conv (block{1,2}.proj, trainer_peft.py:241)."""

@@ -10,6 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F  # noqa: N812
 
 from .. import functional as Fn
+from .. import ops
 from .. import runtime as rt
 
 
@@ -26,15 +27,13 @@ class GlobalContext(nn.Module):
             nn.Conv1d(inner_dim, dim_out, 1),
             nn.Sigmoid(),
         )
-        self._c0, self._c2 = Fn.PackCache(), Fn.PackCache()
 
     def gate_from_rows(self, h: torch.Tensor, link=None) -> torch.Tensor:
         """rows (B, L, C) -> gate fp32 (B, C_out).  link: functional.GateLink shared with the gate * h consumer."""
         pooled = Fn.GCAPoolFn.apply(h, self.to_k.weight, self.to_k.bias, link)
         l0, l2 = self.layers[0], self.layers[2]
-        z = rt.small_linear(pooled, l0.weight, l0.bias, self._c0, "l0")
-        z = rt.small_linear(F.silu(z), l2.weight, l2.bias, self._c2, "l2")
-        return torch.sigmoid(z)
+        z = rt.small_linear(pooled, l0.weight, l0.bias)
+        return rt.small_linear(z, l2.weight, l2.bias, in_act=ops.ACT_SILU, out_act=ops.ACT_SIGMOID)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         h = rt.to_rows(x, rt.compute_dtype(self.to_k.weight.dtype))
@@ -85,17 +84,14 @@ class ResidualBlock(nn.Module):
         self.block2 = Block(dim_out, dim_out)
         self.res_conv = nn.Conv1d(dim_in, dim_out, 1) if dim_in != dim_out else nn.Identity()
         self.se = GlobalContext(dim_out, dim_out)
-        self._cm, self._cr = Fn.PackCache(), Fn.PackCache()
-        self._ss_batched: Optional[torch.Tensor] = None     # set by UNet when it evaluates all FiLM projections in one GEMM
+        self._cr = Fn.PackCache()
 
     def forward_rows(self, x: torch.Tensor, t: Optional[torch.Tensor], c: Optional[torch.Tensor]) -> torch.Tensor:
         ss = None
-        if self._ss_batched is not None:
-            ss = self._ss_batched
-        elif self.mlp is not None and (self.has_time_cond or self.has_cond):
-            emb = torch.cat([e for e in (t, c) if e is not None], dim=-1).float()
+        if self.mlp is not None and (self.has_time_cond or self.has_cond):
+            emb = rt.shared_cat(t, c)                      # cat(t, c): one tensor for all blocks of a forward
             lin = self.mlp[1]
-            ss = rt.small_linear(F.silu(emb), lin.weight, lin.bias, self._cm, "mlp")     # (B, 2C): scale | shift
+            ss = rt.small_linear(emb, lin.weight, lin.bias, in_act=ops.ACT_SILU)          # (B, 2C): scale | shift
         h = self.block1.forward_rows(x, ss)
         h = self.block2.forward_rows(h, None)
         link = Fn.GateLink() if torch.is_grad_enabled() and h.requires_grad else None

@@ -12,6 +12,7 @@ import torch.nn.functional as F  # noqa: N812
 from torch.utils.checkpoint import checkpoint
 
 from .. import functional as Fn
+from .. import ops
 from .. import runtime as rt
 from .residual import ResidualBlock
 from .utils import prob_mask_like
@@ -301,8 +302,7 @@ class UNet(nn.Module):
         self.up_layers = nn.ModuleList([
             UNetBlock(di, do, self.dim_emb, self.dim_emb, i, n_layers, rblocks[i], False, attn_dim_head, attn_heads, attn_kv_heads,
                       attn_context_len // (2 ** (n_layers - i - 1))) for i, (do, di) in enumerate(rev)])
-        self._ct1, self._ct3, self._cc0, self._cc2, self._cf, self._cfilm = (Fn.PackCache() for _ in range(6))
-        self._film_blocks = None
+        self._cf = Fn.PackCache()
 
     def set_gradient_checkpointing(self, value: bool) -> None:
         for name, module in self.named_modules():
@@ -324,49 +324,21 @@ class UNet(nn.Module):
 
     def embed_time(self, t: torch.Tensor) -> torch.Tensor:
         e = self.time_mlp[0](t)
-        e = rt.small_linear(e, self.time_mlp[1].weight, self.time_mlp[1].bias, self._ct1, "t1")
-        return rt.small_linear(F.silu(e), self.time_mlp[3].weight, self.time_mlp[3].bias, self._ct3, "t3")
+        e = rt.small_linear(e, self.time_mlp[1].weight, self.time_mlp[1].bias)
+        return rt.small_linear(e, self.time_mlp[3].weight, self.time_mlp[3].bias, in_act=ops.ACT_SILU)
 
     def embed_cond(self, c: torch.Tensor, cond_mask: torch.Tensor) -> torch.Tensor:
-        e = rt.small_linear(c.float(), self.cond_mlp[0].weight, self.cond_mlp[0].bias, self._cc0, "c0")
-        e = rt.small_linear(F.silu(e), self.cond_mlp[2].weight, self.cond_mlp[2].bias, self._cc2, "c2")
+        e = rt.small_linear(c.float(), self.cond_mlp[0].weight, self.cond_mlp[0].bias)
+        e = rt.small_linear(e, self.cond_mlp[2].weight, self.cond_mlp[2].bias, in_act=ops.ACT_SILU)
         null = self.null_cond.float()[None, :].expand(e.shape[0], -1)
         return torch.where(cond_mask[:, None], e, null)
 
-    def _batched_film(self, t: torch.Tensor, c: torch.Tensor) -> bool:
-        """All FiLM projections Linear(SiLU(cat(t, c))) of the conditioned ResidualBlocks (35 at the default config) share one
-        input: evaluate them as ONE (B, 2E) x (2E, sum 2*C_out) GEMM (and one dgrad / one wgrad in backward) instead of 35
-        M=B launches each way, and hand every block its (scale | shift) slice.  Exact same arithmetic per output element."""
-        if self.training and any(getattr(m, "gradient_checkpointing", False) for m in self.modules()):
-            return False                                   # reentrant checkpointing re-runs blocks outside this scope
-        if self._film_blocks is None:
-            self._film_blocks = [m for m in self.modules() if isinstance(m, ResidualBlock) and m.mlp is not None]
-        blocks = self._film_blocks
-        if not blocks:
-            return False
-        emb = F.silu(torch.cat([t, c], dim=-1).float())
-        w = torch.cat([b.mlp[1].weight for b in blocks], 0)
-        bias = torch.cat([b.mlp[1].bias for b in blocks], 0)
-        ss_all = rt.small_linear(emb, w, bias, self._cfilm, "film_all", vparams=tuple(b.mlp[1].weight for b in blocks))
-        off = 0
-        for b in blocks:
-            n = b.mlp[1].weight.shape[0]
-            b._ss_batched = ss_all[:, off:off + n]
-            off += n
-        return True
-
-    def _clear_film(self) -> None:
-        for b in self._film_blocks or ():
-            b._ss_batched = None
-
     def denoise_rows(self, x_rows: torch.Tensor, a_rows: torch.Tensor, t: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
         """x_rows: stem output (B, L, dim_h); a_rows: audio code (B, L/2^(depth-1), 4*dim_h) -> (B, dim_in_x, L) fp32."""
-        batched = self._batched_film(t, c)
         try:
             return self._denoise_rows(x_rows, a_rows, t, c)
         finally:
-            if batched:
-                self._clear_film()
+            rt.clear_shared_cat()                          # the 35 FiLM projections shared one cat(t, c)
 
     def _denoise_rows(self, x_rows: torch.Tensor, a_rows: torch.Tensor, t: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
         r = x_rows

@@ -370,6 +370,33 @@ def clip_coef(sumsq: torch.Tensor, max_norm: float, base: float, coef: torch.Ten
     call("osuf_clip_coef", _p(sumsq), float(max_norm), float(base), _p(coef), _p(total_norm), _stream())
 
 
+ACT_NONE, ACT_SILU, ACT_SIGMOID = 0, 1, 2
+
+
+def skinny_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mode_dtype: torch.dtype, in_act: int = 0, out_act: int = 0):
+    """y = out_act(in_act(x) W^T + b) for (M, K) fp32 rows and an fp32 master weight (N, K[, 1]) read in place."""
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.is_cuda
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.numel() == N * K
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    call("osuf_skinny_fwd", _DT[mode_dtype], _p(x), x.stride(0), _p(w), _p(bias), _p(y), N, M, N, K, in_act, out_act, _stream())
+    return y
+
+
+def skinny_bwd(dy: torch.Tensor, y: Optional[torch.Tensor], x: torch.Tensor, w: torch.Tensor, mode_dtype: torch.dtype, in_act: int, out_act: int,
+               want_dx: bool, dw_out: Optional[torch.Tensor], db_out: Optional[torch.Tensor], accumulate: bool):
+    """-> dx (or None).  dw_out (N, K[, 1]) fp32 is written (or += when accumulate); db_out (N,) is always added into."""
+    M, K = x.shape
+    N = w.shape[0]
+    assert dy.dtype == torch.float32 and dy.stride(1) == 1 and dy.shape == (M, N)
+    dx = torch.empty((M, K), dtype=torch.float32, device=x.device) if want_dx else None
+    call("osuf_skinny_bwd", _DT[mode_dtype], _p(dy), dy.stride(0), _p(y), N if y is not None else 0, _p(x), x.stride(0), _p(w), _p(dx), K,
+         _p(dw_out), _p(db_out), M, N, K, in_act, out_act, 1 if accumulate else 0, _stream())
+    return dx
+
+
 _DKIND = {"same": 0, "down": 1, "up": 2}
 
 

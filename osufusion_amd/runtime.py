@@ -92,28 +92,29 @@ def cast_rows(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return x if x.dtype == dtype else _CastFn.apply(x, dtype)
 
 
-def small_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], cache: Fn.PackCache, tag: str,
-                 vparams: Optional[tuple] = None) -> torch.Tensor:
-    """(B, K) @ w(N, K)^T + b for the embedding-sized MLPs (time / cond / FiLM / GlobalContext), fp32 in, fp32 out.
+_CAT_MEMO = [None, None, None]
 
-    The GEMM runs in the compute dtype, as the reference does: fp32 run -> exact-f32 MFMA; bf16 autocast -> bf16 operands with
-    fp32 accumulation (torch autocast casts nn.Linear / 1x1 Conv1d to bf16 too).  The f32 MFMA runs at 1/16 of the bf16 rate,
-    which made these 280 M=32 GEMMs cost 18 ms of a 340 ms bf16 step when they were pinned to fp32."""
+
+def shared_cat(t: Optional[torch.Tensor], c: Optional[torch.Tensor]) -> torch.Tensor:
+    """cat((t, c), -1) as fp32, memoised on the identity of (t, c): every conditioned ResidualBlock of one UNet forward gets the
+    same tensor (residual.py:126-127 re-concatenates per block), so autograd sums their gradients into one node."""
+    if _CAT_MEMO[2] is not None and _CAT_MEMO[0] is t and _CAT_MEMO[1] is c:
+        return _CAT_MEMO[2]
+    e = torch.cat([v for v in (t, c) if v is not None], dim=-1).float()
+    _CAT_MEMO[0], _CAT_MEMO[1], _CAT_MEMO[2] = t, c, e
+    return e
+
+
+def clear_shared_cat() -> None:
+    _CAT_MEMO[0] = _CAT_MEMO[1] = _CAT_MEMO[2] = None
+
+
+def small_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], in_act: int = 0, out_act: int = 0) -> torch.Tensor:
+    """out_act(in_act(x) @ w(N, K[, 1])^T + b) for the embedding-sized MLPs (time / cond / FiLM / GlobalContext): fp32 rows in, fp32
+    out, the fp32 master weight read in place by the skinny-linear kernels (csrc/skinny.hip).  in_act: ops.ACT_SILU fuses the
+    SiLU the reference applies to the input (nn.Sequential(SiLU, Linear)); out_act: ops.ACT_SIGMOID fuses GlobalContext's sigmoid.
+
+    The products run in the compute dtype, as the reference's do: fp32 run -> exact-f32 MFMA; bf16 autocast -> operands rounded to
+    bf16, fp32 accumulation (torch autocast casts nn.Linear / 1x1 Conv1d to bf16 too)."""
     require_gpu(x)
-    dt = compute_dtype(w.dtype)
-    K = x.shape[-1]
-    x = x.float()
-    w2 = w.reshape(w.shape[0], -1).float()
-    if K % 8:                                    # e.g. cond_mlp.0: Linear(5, E)
-        padk = 8 - K % 8
-        x = torch.nn.functional.pad(x, (0, padk))
-        w2 = torch.nn.functional.pad(w2, (0, padk))
-    N = w2.shape[0]
-    padn = (-N) % 8
-    if padn:
-        w2 = torch.nn.functional.pad(w2, (0, 0, 0, padn))
-        b = torch.nn.functional.pad(b, (0, padn)) if b is not None else None
-    xr = cast_rows(x.contiguous().unsqueeze(0), dt)
-    y = Fn.ConvFn.apply(xr, w2, b.float() if b is not None else None, cache, "same", (tag, *(vparams if vparams is not None else (w,))))
-    y = cast_rows(y, torch.float32).squeeze(0)
-    return y[:, :N] if padn else y
+    return Fn.SkinnyLinearFn.apply(x.float(), w, b, compute_dtype(w.dtype), in_act, out_act)

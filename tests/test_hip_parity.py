@@ -82,6 +82,42 @@ def test_mfma_layout_exact_integers(dtype):
     assert torch.equal(gw.double(), dy.double().t() @ a.double())
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("M,N,K,in_act,out_act", [(32, 128, 256, 0, 0), (32, 256, 128, 1, 2), (2, 64, 5, 0, 0), (48, 72, 200, 1, 0),
+                                                  (64, 1024, 1024, 1, 2), (7, 33, 17, 0, 2)])
+def test_skinny_linear_kernels(dtype, tol, M, N, K, in_act, out_act):
+    """osuf_skinny_fwd / _bwd (embedding-sized MLPs, fp32 masters read in place) vs torch: y, dx, dW, db; M not a multiple of 32,
+    K not a multiple of 8 (cond_mlp.0 has K=5), fused input SiLU / output sigmoid and their derivatives."""
+    x = T(uniform_pm("sk.x", (M, K), 1.5)).requires_grad_()
+    w = T(uniform_pm("sk.w", (N, K), 1.0 / np.sqrt(K))).requires_grad_()
+    b = T(uniform_pm("sk.b", (N,), 0.2)).requires_grad_()
+    gy = T(uniform_pm("sk.g", (M, N), 1.0))
+    xr, wr, br = (t.detach().double().requires_grad_() for t in (x, w, b))
+    xin = F.silu(xr) if in_act else xr
+    if dtype == torch.bfloat16:                              # the kernel rounds both MFMA operands to bf16 (fp32 accumulate)
+        rnd = lambda t: t + (t.float().bfloat16().double() - t).detach()
+        z = F.linear(rnd(xin), rnd(wr), br)
+    else:
+        z = F.linear(xin, wr, br)
+    yr = torch.sigmoid(z) if out_act else z
+    yr.backward(gy.double())
+    y = Fn.SkinnyLinearFn.apply(x, w, b, dtype, in_act, out_act)
+    y.backward(gy)
+    assert relmax(y, yr) < tol
+    assert relmax(x.grad, xr.grad) < tol * (1 if dtype == torch.float32 else 3)
+    assert relmax(w.grad, wr.grad) < tol * (1 if dtype == torch.float32 else 3)
+    assert relmax(b.grad, br.grad) < 1e-5
+    # direct accumulation into an existing .grad (Trainer path): a second backward doubles it
+    Fn.enable_direct_grads(True)
+    try:
+        g0 = w.grad.clone()
+        y2 = Fn.SkinnyLinearFn.apply(x.detach(), w, b, dtype, in_act, out_act)
+        y2.backward(gy)
+        assert relmax(w.grad, 2 * g0) < 1e-5
+    finally:
+        Fn.enable_direct_grads(False)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("kind,O,I,k", [("same", 40, 72, 3), ("same", 33, 17, 1), ("same", 64, 96, 15), ("same", 8, 40, 7), ("down", 48, 40, 3),
                                         ("up", 24, 100, 3)])
