@@ -32,7 +32,9 @@ STEP_TFLOP = 125.1                      # 3 x 1,303 GFLOP/sample x 32 (SURVEY.md
 # HBM-side bytes per launch of each attention kernel, mean over the 39 launches of one step at the headline shape, from separate
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command (profiles/r01_pmc/bench_{fetch,write}_size_by_kernel.csv);
 # FETCH_SIZE doubled as MI355X_MICROARCH.md "HBM" prescribes for 16-B/lane streams on gfx950.  bench.py cannot run the profiler
-# on itself, so the offline measurement is quoted (algorithmic bytes of the dK/dV kernel over the same mix: 289 MB).
+# on itself, so the offline measurement is quoted (algorithmic bytes of the dK/dV kernel over the same mix: 289 MB).  Re-measured
+# after the kernels were software-pipelined, stand-alone at N=4096 (profiles/r01_pmc2/): dK/dV 2 x 287.0 MiB fetched + 64.0 MiB
+# written = 655 MB, i.e. x 0.4423 (the mix's mean N-weight) = 289.7 MB per launch -- unchanged.
 PMC_TRAFFIC_BYTES = {"osuf_mqa_bwd_dkv": 2 * 129.9e6 + 29.7e6, "osuf_mqa_bwd_dq": 2 * 182.0e6 + 237.5e6, "osuf_mqa_fwd": 2 * 133.4e6 + 219.0e6}
 
 
