@@ -61,11 +61,12 @@ int osuf_colsum(int dtype, const void* Y, long ldy, int M, int N, float* out, hi
 int osuf_gn_finalize(const double* stats, float* mean_rstd, int B, long count, hipStream_t stream);
 int osuf_gn_apply_fwd(int dtype, const void* y, long ldy, void* h, long ldh, const float* mean_rstd, const float* gamma,
                       const float* beta, const float* scale_shift, int M, int C, int L, hipStream_t stream);
-/* T123 [B][3][C] fp32 zeroed scratch; S [B][2] scratch; dss [B][2C] (may be NULL); dgamma/dbeta accumulated into; dbias (may be
- * NULL): gradient of the bias of the conv that produced y (= column sums of dy, residual.py:77 `self.proj`), accumulated into */
+/* T1234 [B][4][C] fp32 zeroed scratch; S [B][2] scratch; dss [B][2C] (may be NULL); dgamma/dbeta accumulated into; dbias (may be
+ * NULL): gradient of the bias of the conv that produced y (= column sums of dy, residual.py:77 `self.proj`), accumulated into;
+ * dyy (may be NULL, needs dbias): column sums of dy*y -- the DoRA magnitude gradient's numerator (lora_layers.py:86-90) */
 int osuf_gn_bwd(int dtype, const void* dh, long lddh, const void* y, long ldy, void* dy, long lddy, const float* mean_rstd,
-                const float* gamma, const float* beta, const float* scale_shift, float* T123, float* S, float* dss,
-                float* dgamma, float* dbeta, float* dbias, int M, int C, int L, hipStream_t stream);
+                const float* gamma, const float* beta, const float* scale_shift, float* T1234, float* S, float* dss,
+                float* dgamma, float* dbeta, float* dbias, float* dyy, int M, int C, int L, hipStream_t stream);
 
 /* ---- LayerNorm    replaces: Attention.norm (modules/unet.py:117,127) ------------------------------------- */
 int osuf_ln_fwd(int dtype, const void* x, long ldx, void* out, long ldo, float* mean_rstd, const float* gamma, const float* beta,

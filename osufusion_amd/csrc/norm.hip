@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* dh, long ld
   const int ch = threadIdx.x % cg.cp, rl = threadIdx.x / cg.cp;
   const int c = ch * 8;
   const int n_begin = blockIdx.x * rows_per_block, n_end = min(L, n_begin + rows_per_block);
-  float t1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t3[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float t1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t3[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t4[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (rl < cg.rp) {
     const float mean = mr[2 * b], rstd = mr[2 * b + 1];
     float g[8], bt[8], sc[8], sh[8];
@@ -95,24 +95,26 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* dh, long ld
         t1[e] += du * xh;
         t2[e] += du;
         t3[e] += xh;
+        t4[e] += xh * xh;
       }
     }
   }
   // reduce over row lanes through LDS, then one atomic per (b, c)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem);            // [3][rp][C]
+  float* red = reinterpret_cast<float*>(smem);            // [4][rp][C]
   if (rl < cg.rp) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       red[(0 * cg.rp + rl) * C + c + e] = t1[e]; red[(1 * cg.rp + rl) * C + c + e] = t2[e]; red[(2 * cg.rp + rl) * C + c + e] = t3[e];
+      red[(3 * cg.rp + rl) * C + c + e] = t4[e];
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
+  for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) {
     const int w = i / C, cc = i - w * C;
     float s = 0.f;
     for (int r = 0; r < cg.rp; ++r) s += red[(w * cg.rp + r) * C + cc];
-    atomic_add_f32(T12 + ((long)b * 3 + w) * C + cc, s);
+    atomic_add_f32(T12 + ((long)b * 4 + w) * C + cc, s);
   }
 }
 
@@ -120,13 +122,15 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* dh, long ld
 // and, when dbias is given, the gradient of the bias of the convolution that produced y -- the column sums of dy -- in closed
 // form from the per-(b, c) sums (T3 = sum_l xhat), instead of a pass over the dy tensor the apply kernel is about to write:
 //   sum_l dy[b,l,c] = rstd_b * ( gamma_c k_bc T2[b,c] - L * S1_b/cnt - (S2_b/cnt) * T3[b,c] )
+// and (dyy, for the DoRA magnitude gradient, lora_layers.py:86-90) sum_l dy*y with y = xhat/rstd + mean, T4 = sum_l xhat^2:
+//   sum_l dy[b,l,c] y[b,l,c] = ( gamma_c k_bc T1 - a1 T3 - a2 T4 ) + mean_b * sum_l dy[b,l,c]
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* T12, const float* gamma, const float* beta, const float* ss,
-                                                              float* S, float* dss, float* dgamma, float* dbeta, float* dbias,
+                                                              float* S, float* dss, float* dgamma, float* dbeta, float* dbias, float* dyy,
                                                               const float* mr, int C, int L, float inv_count) {
   const int b = blockIdx.x;
   float s1 = 0.f, s2 = 0.f;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const float t1 = T12[((long)b * 3 + 0) * C + c], t2 = T12[((long)b * 3 + 1) * C + c];
+    const float t1 = T12[((long)b * 4 + 0) * C + c], t2 = T12[((long)b * 4 + 1) * C + c];
     const float g = gamma[c], bt = beta[c];
     const float k = ss ? 1.f + ss[(long)b * 2 * C + c] : 1.f;
     s1 += g * k * t2;
@@ -143,12 +147,14 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* T12, 
   const float S1 = r1[0] + r1[1] + r1[2] + r1[3], S2 = r2[0] + r2[1] + r2[2] + r2[3];
   if (threadIdx.x == 0) { S[2 * b] = S1; S[2 * b + 1] = S2; }
   if (dbias) {
-    const float rstd = mr[2 * b + 1];
+    const float mean = mr[2 * b], rstd = mr[2 * b + 1];
     const float a1 = S1 * inv_count, a2 = S2 * inv_count;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      const float t2 = T12[((long)b * 3 + 1) * C + c], t3 = T12[((long)b * 3 + 2) * C + c];
-      const float k = ss ? 1.f + ss[(long)b * 2 * C + c] : 1.f;
-      atomic_add_f32(dbias + c, rstd * (gamma[c] * k * t2 - (float)L * a1 - a2 * t3));
+      const float t1 = T12[((long)b * 4 + 0) * C + c], t2 = T12[((long)b * 4 + 1) * C + c], t3 = T12[((long)b * 4 + 2) * C + c];
+      const float gk = gamma[c] * (ss ? 1.f + ss[(long)b * 2 * C + c] : 1.f);
+      const float sdy = rstd * (gk * t2 - (float)L * a1 - a2 * t3);
+      atomic_add_f32(dbias + c, sdy);
+      if (dyy) atomic_add_f32(dyy + c, (gk * t1 - a1 * t3 - a2 * T12[((long)b * 4 + 3) * C + c]) + mean * sdy);
     }
   }
 }
@@ -547,22 +553,23 @@ extern "C" int osuf_gn_apply_fwd(int dtype, const void* y, long ldy, void* h, lo
   return osuf_launch_status();
 }
 
-// T123: [B][3][C] fp32, must be zero on entry.  dss may be null (no FiLM).  dgamma / dbeta / dbias (the latter optional: gradient of
-// the bias of the conv feeding this norm = column sums of dy) are accumulated into.
+// T1234: [B][4][C] fp32, must be zero on entry.  dss may be null (no FiLM).  dgamma / dbeta / dbias (the latter optional: gradient
+// of the bias of the conv feeding this norm = column sums of dy) / dyy (optional, needs dbias: column sums of dy*y) are accumulated into.
 extern "C" int osuf_gn_bwd(int dtype, const void* dh, long lddh, const void* y, long ldy, void* dy, long lddy, const float* mr,
                            const float* gamma, const float* beta, const float* ss, float* T123, float* S, float* dss,
-                           float* dgamma, float* dbeta, float* dbias, int M, int C, int L, hipStream_t stream) {
+                           float* dgamma, float* dbeta, float* dbias, float* dyy, int M, int C, int L, hipStream_t stream) {
   if (bad_c(C) || M <= 0 || L <= 0 || M % L || ldy % 8 || lddh % 8 || lddy % 8) return OSUF_EINVAL;
   const int B = M / L;
   const int chunks = C / 8;
   const int rp = 256 / chunks;
   const int rows_per_block = 64;
-  const size_t lds = (size_t)3 * rp * C * sizeof(float);
+  if (dyy && !dbias) return OSUF_EINVAL;
+  const size_t lds = (size_t)4 * rp * C * sizeof(float);
   const float inv_count = 1.0f / ((float)L * (float)C);
   DISPATCH_T(dtype, hipLaunchKernelGGL(gn_bwd_reduce_kernel<T>, dim3((L + rows_per_block - 1) / rows_per_block, B), dim3(256), lds,
                                        stream, (const T*)dh, lddh, (const T*)y, ldy, mr, gamma, beta, ss, T123, C, L, rows_per_block));
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, stream, T123, gamma, beta, ss, S, dss, dgamma, dbeta, dbias, mr, C, L,
-                     inv_count);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, stream, T123, gamma, beta, ss, S, dss, dgamma, dbeta, dbias, dyy, mr,
+                     C, L, inv_count);
   DISPATCH_T(dtype, hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(ew_grid((long)M * chunks)), dim3(256), 0, stream, (const T*)dh,
                                        lddh, (const T*)y, ldy, (T*)dy, lddy, mr, gamma, beta, ss, S, M, C, L, inv_count));
   return osuf_launch_status();

@@ -205,12 +205,13 @@ class Adapter:
         return self._eff[1], self._eff[2]
 
 
-def adapter_grads(ad: Adapter, dy, x, y, bias, kind: str, cache: PackCache):
+def adapter_grads(ad: Adapter, dy, x, y, bias, kind: str, cache: PackCache, sums=None):
     """Gradients of (lora_A, lora_B, magnitude) from rows dy (B, Lout, O), the layer input x (B, Lin, I) and the layer output
     y (B, Lout, O) (= g*z + bias, as produced by the forward).  All GEMMs are rank-r:
         u  = A(x)                       (B, Lout, r)   tap-GEMM, N = r
         du = dy . (s g B)               (B, Lout, r)   K = O
-        dB = s g (dy^T u),  dA = du^T x (per tap),  dm = (sum dy*y - bias * sum dy) / m      [g = m/norm, norm detached]"""
+        dB = s g (dy^T u),  dA = du^T x (per tap),  dm = (sum dy*y - bias * sum dy) / m      [g = m/norm, norm detached]
+    sums: (sum_m dy*y, sum_m dy) per output channel when the caller already has them (BlockFn: from the GroupNorm backward)."""
     B_, Lin, I = x.shape
     O = dy.shape[-1]
     r = ad.a.shape[0]
@@ -230,9 +231,12 @@ def adapter_grads(ad: Adapter, dy, x, y, bias, kind: str, cache: PackCache):
         da = da if conv else da[0]
         dm = None
         if ad.m is not None:
-            s1 = ops.wcolsum(dy, y, None, B_, Lout).sum(0)
-            if bias is not None:
-                s1 = s1 - bias.detach().float() * ops.colsum(dy, O)
+            if sums is not None:                           # (sum dy*y, sum dy) already produced by the GroupNorm backward
+                s1 = sums[0] - bias.detach().float() * sums[1] if bias is not None else sums[0]
+            else:
+                s1 = ops.wcolsum(dy, y, None, B_, Lout).sum(0)
+                if bias is not None:
+                    s1 = s1 - bias.detach().float() * ops.colsum(dy, O)
             dm = (s1 / ad.m.detach().float().reshape(-1)).reshape(ad.m.shape)
     return da.reshape(ad.a.shape), db.reshape(ad.b.shape), dm
 
@@ -352,20 +356,26 @@ class BlockFn(torch.autograd.Function):
         direct_norm = tg is not None and tb is not None
         # conv-bias gradient (= column sums of dy) comes out of the GroupNorm backward in closed form: no extra pass over dy
         bias = ctx.bias_ref
+        ad = ctx.adapter
         db = None
-        tbias = None
+        tbias = dyy = sdy = None
         if need[2] and bias is not None:
             tbias = grad_target(bias)
             if tbias is None:
                 db = tbias = torch.zeros(bias.shape, dtype=torch.float32, device=dh.device)
+        want_dm = ad is not None and ad.m is not None and need[10]
+        if want_dm:                                        # DoRA magnitude: column sums of dy*y and of dy, same closed form
+            dyy = torch.zeros(y.shape[-1], dtype=torch.float32, device=dh.device)
+            sdy = tbias if db is not None else torch.zeros(y.shape[-1], dtype=torch.float32, device=dh.device)
         dy, dgamma, dbeta, dss = ops.gn_bwd(_rc(dh), y, mr, gamma, beta, ss, L, tg if direct_norm else None, tb if direct_norm else None,
-                                            tbias)
+                                            sdy if want_dm else tbias, dyy)
         if tbias is not None and db is None:
+            if want_dm:
+                tbias.add_(sdy)
             grad_done(bias)
         if direct_norm:
             grad_done(gamma); grad_done(beta)
             dgamma = dbeta = None
-        ad = ctx.adapter
         dx = None
         if need[0]:
             dx = conv_dgrad(dy, ad.effective()[0], ctx.cache, "same", L, vp=("dora", *ad.params)) if ad is not None \
@@ -373,7 +383,7 @@ class BlockFn(torch.autograd.Function):
         dw = conv_wgrad(dy, x, w, "same") if need[1] else None
         da = dlb = dm = None
         if ad is not None and (need[8] or need[9] or need[10]):
-            da, dlb, dm = adapter_grads(ad, dy, x, y, ctx.bias_ref, "same", ctx.cache)
+            da, dlb, dm = adapter_grads(ad, dy, x, y, ctx.bias_ref, "same", ctx.cache, sums=(dyy, sdy) if want_dm else None)
         return dx, dw, db, dgamma if need[3] else None, dbeta if need[4] else None, dss, None, None, da, dlb, dm
 
 

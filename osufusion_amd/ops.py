@@ -176,21 +176,23 @@ def gn_apply(y: torch.Tensor, mr: torch.Tensor, gamma: torch.Tensor, beta: torch
 
 
 def gn_bwd(dh: torch.Tensor, y: torch.Tensor, mr: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ss: Optional[torch.Tensor], L: int,
-           dgamma_out: Optional[torch.Tensor] = None, dbeta_out: Optional[torch.Tensor] = None, dbias_out: Optional[torch.Tensor] = None):
+           dgamma_out: Optional[torch.Tensor] = None, dbeta_out: Optional[torch.Tensor] = None, dbias_out: Optional[torch.Tensor] = None,
+           dyy_out: Optional[torch.Tensor] = None):
     """dgamma_out / dbeta_out (fp32 (C,)) are accumulated into when given (parameter .grad buffers); dbias_out (fp32 (C,)) receives
-    (+=) the gradient of the bias of the conv that produced y, in closed form from the per-(b, c) sums (no pass over dy)."""
+    (+=) the gradient of the bias of the conv that produced y, in closed form from the per-(b, c) sums (no pass over dy); dyy_out
+    (fp32 (C,), needs dbias_out) likewise the column sums of dy * y (DoRA magnitude gradient)."""
     M, C, ldy = _rows(y)
     B = M // L
     dev = y.device
     dy = torch.empty(y.shape, dtype=y.dtype, device=dev)
-    T12 = torch.zeros((B, 3, C), dtype=torch.float32, device=dev)
+    T12 = torch.zeros((B, 4, C), dtype=torch.float32, device=dev)
     S = torch.empty((B, 2), dtype=torch.float32, device=dev)
     dss = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if ss is not None else None
     if dgamma_out is None or dbeta_out is None:
         dgb = torch.zeros((2, C), dtype=torch.float32, device=dev)
         dgamma_out, dbeta_out = dgb[0], dgb[1]
     call("osuf_gn_bwd", dt_of(y), _p(dh), _rows(dh)[2], _p(y), ldy, _p(dy), C, _p(mr), _p(gamma), _p(beta), _p(ss), _p(T12), _p(S),
-         _p(dss), _p(dgamma_out), _p(dbeta_out), _p(dbias_out), M, C, L, _stream())
+         _p(dss), _p(dgamma_out), _p(dbeta_out), _p(dbias_out), _p(dyy_out), M, C, L, _stream())
     return dy, dgamma_out, dbeta_out, dss
 
 
