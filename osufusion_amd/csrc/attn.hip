@@ -312,7 +312,7 @@ __global__ __launch_bounds__(NW * 64) void mqa_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float p = fast_exp2(fmaf(s[kt][r], c, -L2));
-        s[kt][r] = p * (dp[kt][r] - dl) * a.scale;
+        s[kt][r] = p * (dp[kt][r] - dl);          // * scale folded into the final store
       }
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(NW * 64) void mqa_bwd_dq_kernel(AttnArgs a) {
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        float v4[4] = {acc[dt][4 * g], acc[dt][4 * g + 1], acc[dt][4 * g + 2], acc[dt][4 * g + 3]};
+        float v4[4] = {acc[dt][4 * g] * a.scale, acc[dt][4 * g + 1] * a.scale, acc[dt][4 * g + 2] * a.scale, acc[dt][4 * g + 3] * a.scale};
         store4(a.dq + m * a.lddq + h * D + dt * 32 + 8 * g + 4 * lh, v4);
       }
   }
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_dq_pipe_kernel(AttnArgs a) {
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * ks + e;
         float p = fast_exp2(fmaf(sc[kt][r], c, -L2));
-        sc[kt][r] = p * (dpc[kt][r] - dl) * a.scale;
+        sc[kt][r] = p * (dpc[kt][r] - dl);       // * scale folded into the final store
         asm volatile("" : "+v"(sc[kt][r]));            // keep the slice HERE (its only consumer is the conversion at the end of the
       }                                                  // iteration, and code sinking would otherwise move all 32 exps behind the MFMAs)
       OSUF_FENCE;
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_dq_pipe_kernel(AttnArgs a) {
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        float v4[4] = {acc[dt][4 * g], acc[dt][4 * g + 1], acc[dt][4 * g + 2], acc[dt][4 * g + 3]};
+        float v4[4] = {acc[dt][4 * g] * a.scale, acc[dt][4 * g + 1] * a.scale, acc[dt][4 * g + 2] * a.scale, acc[dt][4 * g + 3] * a.scale};
         store4(a.dq + m * a.lddq + h * D + dt * 32 + 8 * g + 4 * lh, v4);
       }
   }
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(NW * 64) void mqa_bwd_dkv_kernel(AttnArgs a) {
           const int r = 4 * g + e;
           float p = fast_exp2(fmaf(s[r], c, -l4[e]));
           s[r] = p;
-          ds[r] = p * (dp[r] - d4[e]) * a.scale;
+          ds[r] = p * (dp[r] - d4[e]);              // * scale folded into the final store
         }
       }
     }
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(NW * 64) void mqa_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d0 = dt * 32 + 8 * g + 4 * lh;
-        float k4[4] = {dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]};
+        float k4[4] = {dk[dt][4 * g] * a.scale, dk[dt][4 * g + 1] * a.scale, dk[dt][4 * g + 2] * a.scale, dk[dt][4 * g + 3] * a.scale};
         float v4[4] = {dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]};
         store4(a.dk + m * a.lddk + d0, k4);
         store4(a.dv + m * a.lddk + d0, v4);
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_pipe_kernel(AttnArgs a) {
         const int r = 4 * g + e;
         float p = fast_exp2(fmaf(sc[r], c, -l4[g][e]));
         sc[r] = p;
-        ds[r] = p * (dpc[r] - d4[g][e]) * a.scale;
+        ds[r] = p * (dpc[r] - d4[g][e]);         // * scale folded into the final store
       }
     };
     OSUF_FENCE;
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_pipe_kernel(AttnArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d0 = dt * 32 + 8 * g + 4 * lh;
-        float k4[4] = {dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]};
+        float k4[4] = {dk[dt][4 * g] * a.scale, dk[dt][4 * g + 1] * a.scale, dk[dt][4 * g + 2] * a.scale, dk[dt][4 * g + 3] * a.scale};
         float v4[4] = {dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]};
         store4(a.dk + m * a.lddk + d0, k4);
         store4(a.dv + m * a.lddk + d0, v4);
