@@ -148,6 +148,47 @@ class FusedAdamW:
         return self.total_norm * grad_scale
 
 
+    # -- torch.optim.AdamW-format state (checkpoint.pt["optimizer_state_dict"], trainer.py:163-171,189-199) ----------------
+    def _model_order(self, module: nn.Module) -> List[int]:
+        """flat index of each trainable parameter, in module.parameters() order (the order torch.optim indexes them in)."""
+        pos = {id(p): i for i, p in enumerate(self.flat.params)}
+        return [pos[id(p)] for p in module.parameters() if p.requires_grad]
+
+    def state_dict(self, module: nn.Module) -> dict:
+        order = self._model_order(module)
+        state = {}
+        if self.step_count > 0:
+            for k, i in enumerate(order):
+                p, o = self.flat.params[i], self.flat.offsets[i]
+                state[k] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[o:o + p.numel()].view_as(p).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view_as(p).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(order)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, module: nn.Module, sd: dict) -> None:
+        order = self._model_order(module)
+        group = sd["param_groups"][0]
+        if len(group["params"]) != len(order):
+            raise ValueError(f"optimizer state has {len(group['params'])} parameters, the model has {len(order)} trainable ones")
+        self.lr, self.betas, self.eps, self.weight_decay = group["lr"], tuple(group["betas"]), group["eps"], group["weight_decay"]
+        steps = set()
+        with torch.no_grad():
+            for k, i in enumerate(order):
+                st = sd["state"].get(k)
+                if st is None:
+                    continue
+                p, o = self.flat.params[i], self.flat.offsets[i]
+                self.exp_avg[o:o + p.numel()].view_as(p).copy_(st["exp_avg"])
+                self.exp_avg_sq[o:o + p.numel()].view_as(p).copy_(st["exp_avg_sq"])
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ; the fused kernel keeps one step count for all parameters")
+        self.step_count = steps.pop() if steps else 0
+
+
 def cosine_warmup_lr(step: int, base_lr: float, warmup: int, total: int, num_cycles: float = 0.5) -> float:
     """diffusers.get_cosine_schedule_with_warmup as called at trainer.py:231-236."""
     if step < warmup:
@@ -184,3 +225,15 @@ class Trainer:
         self.reducer.finish()
         total_norm = self.opt.step(grad_scale=1.0 / self.reducer.world, clip_grad_norm=self.clip)
         return loss.detach(), total_norm
+
+    # -- checkpoint.pt in the reference's layout (trainer.py:148-203): resumable by either trainer ------------------------
+    def state_dict(self, scheduler_state: Optional[dict] = None) -> dict:
+        return {"model_state_dict": self.model.state_dict(), "optimizer_state_dict": self.opt.state_dict(self.model),
+                "scheduler_state_dict": scheduler_state if scheduler_state is not None else {}, "rng_state": torch.get_rng_state()}
+
+    def load_state_dict(self, checkpoint: dict, strict: bool = True) -> None:
+        self.model.load_state_dict(checkpoint["model_state_dict"], strict=strict)      # copies into the flat buffer's views
+        self.opt.load_state_dict(self.model, checkpoint["optimizer_state_dict"])
+        if "rng_state" in checkpoint and checkpoint["rng_state"] is not None:
+            torch.set_rng_state(checkpoint["rng_state"].cpu())
+        Fn.bump_weight_epoch()
