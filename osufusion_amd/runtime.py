@@ -92,21 +92,24 @@ def cast_rows(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return x if x.dtype == dtype else _CastFn.apply(x, dtype)
 
 
-_CAT_MEMO = [None, None, None]
+_CAT_MEMO = [None, None, None, None]
 
 
 def shared_cat(t: Optional[torch.Tensor], c: Optional[torch.Tensor]) -> torch.Tensor:
-    """cat((t, c), -1) as fp32, memoised on the identity of (t, c): every conditioned ResidualBlock of one UNet forward gets the
-    same tensor (residual.py:126-127 re-concatenates per block), so autograd sums their gradients into one node."""
-    if _CAT_MEMO[2] is not None and _CAT_MEMO[0] is t and _CAT_MEMO[1] is c:
+    """cat((t, c), -1) as fp32, memoised on the identity of (t, c) and on the autograd mode: every conditioned ResidualBlock of one
+    UNet forward gets the same tensor (residual.py:126-127 re-concatenates per block), so autograd sums their gradients into one
+    node.  The grad mode is part of the key: under reentrant activation checkpointing the first pass runs without grad, and a
+    tensor memoised there must not be handed to the blocks outside the checkpointed region (it carries no graph)."""
+    mode = torch.is_grad_enabled()
+    if _CAT_MEMO[2] is not None and _CAT_MEMO[0] is t and _CAT_MEMO[1] is c and _CAT_MEMO[3] == mode:
         return _CAT_MEMO[2]
     e = torch.cat([v for v in (t, c) if v is not None], dim=-1).float()
-    _CAT_MEMO[0], _CAT_MEMO[1], _CAT_MEMO[2] = t, c, e
+    _CAT_MEMO[0], _CAT_MEMO[1], _CAT_MEMO[2], _CAT_MEMO[3] = t, c, e, mode
     return e
 
 
 def clear_shared_cat() -> None:
-    _CAT_MEMO[0] = _CAT_MEMO[1] = _CAT_MEMO[2] = None
+    _CAT_MEMO[0] = _CAT_MEMO[1] = _CAT_MEMO[2] = _CAT_MEMO[3] = None
 
 
 def small_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], in_act: int = 0, out_act: int = 0) -> torch.Tensor:

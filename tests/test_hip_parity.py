@@ -468,6 +468,56 @@ def test_unet_bf16_vs_oracle_emulation(golden_dir, case):
     assert e32 < 3 * floor + 1e-2
 
 
+def test_masked_loss_ragged_batch_and_length_assert(golden_dir):
+    """trainer.py:74-95 pads a batch to its longest sample and passes orig_len; diffusion.py:104-110 masks the loss with it and
+    diffusion.py:86 raises AssertionError on a length mismatch (which trainer.py:296-299 catches to skip the batch)."""
+    meta, cfgd, model = _build_model("unet_tiny", golden_dir)
+    cfg = O.UNetConfig(**cfgd)
+    p = O.make_params(cfg, prefix="unet.")
+    B_, L = meta["B"], meta["L"]
+    x, a, c, t, noise = (torch.from_numpy(v) for v in synth_inputs("ragged", B_, L))
+    orig = torch.tensor([L, L // 2 - 5][:B_])
+    for b in range(B_):                                                  # what collate_fn produces
+        x[b, :, orig[b]:] = -1.0
+        a[b, :, orig[b]:] = -23.0
+    ref = DO.training_loss(p, cfg, x, a, c, noise, t, cond_drop_prob=0.0, orig_len=orig)
+    ref_unmasked = DO.training_loss(p, cfg, x, a, c, noise, t, cond_drop_prob=0.0)
+    with oa.forced_compute_dtype(torch.float32):
+        loss = model.loss_with(x.to(DEV), a.to(DEV), c.to(DEV), noise.to(DEV), t.to(DEV), orig_len=orig.to(DEV), cond_drop_prob=0.0)
+        loss.backward()
+    assert abs(loss.item() - ref.item()) < TOL * abs(ref.item())
+    assert abs(ref.item() - ref_unmasked.item()) > 3 * TOL * abs(ref.item())           # the mask matters in this fixture
+    g = model.unet.final_conv.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0
+    with pytest.raises(AssertionError):
+        model(x.to(DEV), a[..., : L - 16].contiguous().to(DEV), c.to(DEV))
+
+
+def test_gradient_checkpointing_matches_plain_backward(golden_dir):
+    """UNet.set_gradient_checkpointing (unet.py:452-456, reentrant checkpoint of every UNetBlock body, unet.py:260-261): same loss
+    and gradients as the plain backward (fp32 compute; differences are summation order only)."""
+    meta, cfgd, model = _build_model("unet_tiny", golden_dir)
+    x, a, c, t, noise = (T(v) for v in synth_inputs("unet_tiny", meta["B"], meta["L"]))
+    model.train()
+    with oa.forced_compute_dtype(torch.float32):
+        l0 = model.loss_with(x, a, c, noise, t, cond_drop_prob=0.0)
+        l0.backward()
+    ref = {k: q.grad.detach().clone() for k, q in model.named_parameters()}
+    for q in model.parameters():
+        q.grad = None
+    model.unet.set_gradient_checkpointing(True)
+    assert any(getattr(m, "gradient_checkpointing", False) for m in model.modules())
+    with oa.forced_compute_dtype(torch.float32):
+        l1 = model.loss_with(x, a, c, noise, t, cond_drop_prob=0.0)
+        l1.backward()
+    assert abs(l0.item() - l1.item()) < 1e-5 * abs(l0.item())
+    gmax = max(v.abs().max().item() for v in ref.values())
+    errs = {k: ((q.grad - ref[k]).abs().max() / (ref[k].abs().max() + 1e-4 * gmax)).item() for k, q in model.named_parameters()}
+    worst_k = max(errs, key=errs.get)
+    report("gradient_checkpointing_vs_plain", max_rel=errs[worst_k])
+    assert errs[worst_k] < 2e-2, (worst_k, errs[worst_k], sorted(errs, key=errs.get)[-8:])   # noise floor as in the direct-accumulation test
+
+
 def test_direct_grad_accumulation_matches_autograd(golden_dir):
     """Trainer path (kernels add straight into the flat .grad buffer, autograd sees None) == plain autograd gradients.
     fp32 compute so that only summation order differs; errors are measured against each tensor's own scale plus a floor at
