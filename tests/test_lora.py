@@ -258,3 +258,37 @@ def test_unet_dora_finetune_step_vs_oracle(dtype, tol):
             assert changed == ("lora_" in n), n
     finally:
         Fn.enable_direct_grads(False)
+
+
+@gpu
+def test_merged_model_equals_adapted_model_on_gpu():
+    """PeftModel.merge_and_unload (trainer_peft.py:161-164): after folding the DoRA adapters into the base weights the plain UNet
+    computes what the adapted one did (inference path of a fine-tuned model), and the module tree is the reference's again."""
+    import osufusion_amd as oa
+    cfg = O.UNetConfig(dim_in_x=6, dim_in_a=96, dim_in_c=5, **TINY)
+    p = O.make_params(cfg)
+    net = U.UNet(6, 96, 5, **TINY)
+    net.load_state_dict(p, strict=True)
+    net.to(DEV).eval()
+    n_keys = len(net.state_dict())
+    LL.get_peft_model(net, LL.LoraConfig(r=8, lora_alpha=16, use_dora=True))
+    mods = dict(net.named_modules())
+    for t in LO.target_names(list(p)):
+        a, b, m = _adapter_tensors(t, p[t + ".weight"].shape, 8, p[t + ".weight"], True)
+        with torch.no_grad():
+            mods[t].lora_A["default"].weight.copy_(a); mods[t].lora_B["default"].weight.copy_(b)
+            mods[t].lora_magnitude_vector["default"].weight.copy_(m)
+    x, a_, c, t_, _ = (torch.from_numpy(v).to(DEV) for v in synth_inputs("lora_merge", 2, 256))
+    with torch.no_grad(), oa.forced_compute_dtype(torch.float32):
+        y_adapted = net(x, a_, t_, c)
+        base_only = None
+        for m in LL.lora_modules(net):
+            m.disable_adapters = True
+        base_only = net(x, a_, t_, c)
+        for m in LL.lora_modules(net):
+            m.disable_adapters = False
+        LL.merge_and_unload(net)
+        assert len(net.state_dict()) == n_keys and not LL.lora_modules(net)
+        y_merged = net(x, a_, t_, c)
+    assert _rel(y_merged, y_adapted) < 1e-3
+    assert _rel(base_only, y_adapted) > 1e-2                               # the adapters do change the function in this fixture
