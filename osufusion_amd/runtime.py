@@ -120,4 +120,7 @@ def small_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], in
     The products run in the compute dtype, as the reference's do: fp32 run -> exact-f32 MFMA; bf16 autocast -> operands rounded to
     bf16, fp32 accumulation (torch autocast casts nn.Linear / 1x1 Conv1d to bf16 too)."""
     require_gpu(x)
-    return Fn.SkinnyLinearFn.apply(x.float(), w, b, compute_dtype(w.dtype), in_act, out_act)
+    dt = compute_dtype(w.dtype)
+    if w.dtype != torch.float32:                           # a model cast with .to(bfloat16): the kernels read fp32 masters
+        w, b = w.float(), (b.float() if b is not None else None)
+    return Fn.SkinnyLinearFn.apply(x.float(), w, b, dt, in_act, out_act)
