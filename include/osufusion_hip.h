@@ -100,12 +100,15 @@ int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, const void* v
                  float* lse2, int B, int H, int N, int head_dim, float scale, hipStream_t stream);
 int osuf_attn_delta(const void* dout, long lddo, const void* o, long ldo, int o_dtype, float* delta, int B, int H, int N,
                     int head_dim, hipStream_t stream);
+/* dq / dk / dv are written in out_dtype (OSUF_DT_F32 or OSUF_DT_BF16).  rope_cos / rope_sin ([N][32] fp32, or both NULL): q and k
+ * were rotated by apply_rotary_pos_emb (attention.py:52-58) before the attention; with the tables given, dq and dk come out as
+ * gradients of the UN-rotated projections (the rotation's transpose rides the epilogue; dv is never rotated). */
 int osuf_mqa_bwd_dq(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
-                    const float* lse2, const float* delta, float* dq, long lddq, int B, int H, int N, int head_dim, float scale,
-                    hipStream_t stream);
+                    const float* lse2, const float* delta, void* dq, long lddq, int B, int H, int N, int head_dim, float scale,
+                    int out_dtype, const float* rope_cos, const float* rope_sin, hipStream_t stream);
 int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
-                     const float* lse2, const float* delta, float* dk, float* dv, long lddk, int B, int H, int N, int head_dim,
-                     float scale, hipStream_t stream);
+                     const float* lse2, const float* delta, void* dk, void* dv, long lddk, int B, int H, int N, int head_dim,
+                     float scale, int out_dtype, const float* rope_cos, const float* rope_sin, hipStream_t stream);
 
 /* ---- layout / scheduler / optimizer (elementwise.hip) ----------------------------------------------------------
  * replaces: the (B,C,L) <-> (B,L,C) rearranges (modules/unet.py:180,183) at the model boundary, torch.cat (unet.py:500,

@@ -67,6 +67,40 @@ __device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& a, int sub) {
   return __builtin_convertvector(v, bf16x8);
 }
 
+// Epilogue of the backward kernels: one row's 64 gradient values (acc[0]: d < 32, acc[1]: d >= 32, this lane holding
+// d = 8g + 4*(lane>>5) + e of each half) times `mul`, optionally mapped through the transpose of the RoPE rotation
+// (apply_rotary_pos_emb, attention.py:52-58: y1 = x1 c - x2 s, y2 = x2 c + x1 s  =>  dx1 = dy1 c + dy2 s, dx2 = dy2 c - dy1 s),
+// stored as fp32 or bf16.  Fusing this here removes the fp32 round trip of the whole (B, N, (H+2)*64) gradient through HBM.
+template <typename TO>
+__device__ __forceinline__ void store_grad_row(TO* row, const f32x16 (&acc)[2], float mul, const float* cs_row, const float* sn_row, int lh) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int d0 = 8 * g + 4 * lh;
+    float y1[4] = {acc[0][4 * g] * mul, acc[0][4 * g + 1] * mul, acc[0][4 * g + 2] * mul, acc[0][4 * g + 3] * mul};
+    float y2[4] = {acc[1][4 * g] * mul, acc[1][4 * g + 1] * mul, acc[1][4 * g + 2] * mul, acc[1][4 * g + 3] * mul};
+    if (cs_row != nullptr) {
+      float cs[4], sn[4];
+      load4(cs_row + d0, cs);
+      load4(sn_row + d0, sn);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a1 = y1[e] * cs[e] + y2[e] * sn[e];
+        const float a2 = y2[e] * cs[e] - y1[e] * sn[e];
+        y1[e] = a1; y2[e] = a2;
+      }
+    }
+    store4(row + d0, y1);
+    store4(row + 32 + d0, y2);
+  }
+}
+__device__ __forceinline__ void store_grad(void* base, long ld, long m, int col0, int is_bf16, const f32x16 (&acc)[2], float mul,
+                                           const float* rcos, const float* rsin, int n, int lh) {
+  const float* cs = rcos ? rcos + (long)n * 32 : nullptr;
+  const float* sn = rcos ? rsin + (long)n * 32 : nullptr;
+  if (is_bf16) store_grad_row(reinterpret_cast<bf16_t*>(base) + m * ld + col0, acc, mul, cs, sn, lh);
+  else store_grad_row(reinterpret_cast<float*>(base) + m * ld + col0, acc, mul, cs, sn, lh);
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 struct AttnArgs {
@@ -76,8 +110,10 @@ struct AttnArgs {
   float* lse2;                                  // [B][H][N] log2-domain logsumexp of (s * scale * log2e)
   const bf16_t* dout; long lddo;                // backward
   const float* delta;                           // [B][H][N]
-  float* dq; long lddq;                         // fp32 [B*N][lddq], head h at h*64
-  float* dk; float* dv; long lddk;              // fp32 [B*N][lddk]
+  void* dq; long lddq;                          // [B*N][lddq], head h at h*64; fp32, or bf16 when g_bf16
+  void* dk; void* dv; long lddk;                // [B*N][lddk]
+  int g_bf16;                                   // gradient output element type
+  const float* rcos; const float* rsin;         // [N][32] RoPE tables: when set, dQ / dK are stored as gradients of the UN-rotated q / k
   int B, H, N;
   float scale;
 };
@@ -324,16 +360,7 @@ __global__ __launch_bounds__(NW * 64) void mqa_bwd_dq_kernel(AttnArgs a) {
     if (j + 1 < ntiles) st.store(smem + ((j + 1) & 1) * 16384, smem + ((j + 1) & 1) * 16384 + 8192, tid);
     __syncthreads();
   }
-  if (qok) {
-    const long m = (long)b * a.N + qrow;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float v4[4] = {acc[dt][4 * g] * a.scale, acc[dt][4 * g + 1] * a.scale, acc[dt][4 * g + 2] * a.scale, acc[dt][4 * g + 3] * a.scale};
-        store4(a.dq + m * a.lddq + h * D + dt * 32 + 8 * g + 4 * lh, v4);
-      }
-  }
+  if (qok) store_grad(a.dq, a.lddq, (long)b * a.N + qrow, h * D, a.g_bf16, acc, a.scale, a.rcos, a.rsin, qrow, lh);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -473,16 +500,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_dq_pipe_kernel(AttnArgs a) {
     if (j + 1 < ntiles) iter(j + 1, j & 3, (j + 2) & 3, (j + 3) & 3, s1, dp1, s0, dp0, dfp);
   }
   dq_plain((ntiles - 1) & 3, dfp);
-  if (qok) {
-    const long m = (long)b * a.N + qrow;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float v4[4] = {acc[dt][4 * g] * a.scale, acc[dt][4 * g + 1] * a.scale, acc[dt][4 * g + 2] * a.scale, acc[dt][4 * g + 3] * a.scale};
-        store4(a.dq + m * a.lddq + h * D + dt * 32 + 8 * g + 4 * lh, v4);
-      }
-  }
+  if (qok) store_grad(a.dq, a.lddq, (long)b * a.N + qrow, h * D, a.g_bf16, acc, a.scale, a.rcos, a.rsin, qrow, lh);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -622,17 +640,8 @@ __global__ __launch_bounds__(NW * 64) void mqa_bwd_dkv_kernel(AttnArgs a) {
     if (DBG != 2) __syncthreads();
   }
   if (kok) {
-    const long m = (long)b * a.N + key;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = dt * 32 + 8 * g + 4 * lh;
-        float k4[4] = {dk[dt][4 * g] * a.scale, dk[dt][4 * g + 1] * a.scale, dk[dt][4 * g + 2] * a.scale, dk[dt][4 * g + 3] * a.scale};
-        float v4[4] = {dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]};
-        store4(a.dk + m * a.lddk + d0, k4);
-        store4(a.dv + m * a.lddk + d0, v4);
-      }
+    store_grad(a.dk, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dk, a.scale, a.rcos, a.rsin, key, lh);
+    store_grad(a.dv, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dv, 1.f, nullptr, nullptr, key, lh);
   }
 }
 
@@ -806,17 +815,8 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_pipe_kernel(AttnArgs a) {
     slot = sC;
   }
   if (kok) {
-    const long m = (long)b * a.N + key;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = dt * 32 + 8 * g + 4 * lh;
-        float k4[4] = {dk[dt][4 * g] * a.scale, dk[dt][4 * g + 1] * a.scale, dk[dt][4 * g + 2] * a.scale, dk[dt][4 * g + 3] * a.scale};
-        float v4[4] = {dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]};
-        store4(a.dk + m * a.lddk + d0, k4);
-        store4(a.dv + m * a.lddk + d0, v4);
-      }
+    store_grad(a.dk, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dk, a.scale, a.rcos, a.rsin, key, lh);
+    store_grad(a.dv, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dv, 1.f, nullptr, nullptr, key, lh);
   }
 }
 
@@ -966,15 +966,16 @@ extern "C" int osuf_attn_delta(const void* dout, long lddo, const void* o, long 
   return osuf_launch_status();
 }
 
-// dq: fp32 [B*N][lddq], head h at columns h*64
+// dq: [B*N][lddq] in out_dtype, head h at columns h*64; rope_cos / rope_sin ([N][32], or both NULL): store the gradient of the un-rotated q
 extern "C" int osuf_mqa_bwd_dq(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
-                               const float* lse2, const float* delta, float* dq, long lddq, int B, int H, int N, int head_dim, float scale,
-                               hipStream_t stream) {
+                               const float* lse2, const float* delta, void* dq, long lddq, int B, int H, int N, int head_dim, float scale,
+                               int out_dtype, const float* rope_cos, const float* rope_sin, hipStream_t stream) {
   AttnArgs a;
   int rc = fill_bwd_args(a, q, ldq, k, ldk, v, ldv, dout, lddo, lse2, delta, B, H, N, head_dim, scale);
   if (rc) return rc;
-  if (lddq % 4 || !al16(dq)) return OSUF_EINVAL;
-  a.dq = dq; a.lddq = lddq;
+  if (lddq % 8 || !al16(dq) || (out_dtype != OSUF_DT_F32 && out_dtype != OSUF_DT_BF16) || ((rope_cos == nullptr) != (rope_sin == nullptr)))
+    return OSUF_EINVAL;
+  a.dq = dq; a.lddq = lddq; a.g_bf16 = out_dtype == OSUF_DT_BF16; a.rcos = rope_cos; a.rsin = rope_sin;
   const int nvb = ((N + 31) / 32) * H;
   if (attn_waves() == 4) hipLaunchKernelGGL(mqa_bwd_dq_kernel<4>, dim3((nvb + 3) / 4, B), dim3(256), 32768, stream, a);
   // the pipelined kernel (2 waves/SIMD, 256 VGPRs) wins once the key loop is long: +4.5 % at N=4096, even at 2048, -3 % at <= 1024
@@ -987,15 +988,17 @@ extern "C" int osuf_mqa_bwd_dq(const void* q, long ldq, const void* k, long ldk,
   return osuf_launch_status();
 }
 
-// dk, dv: fp32 [B*N][lddk]
+// dk, dv: [B*N][lddk] in out_dtype; rope tables as for dq (applied to dk only)
 extern "C" int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
-                                const float* lse2, const float* delta, float* dk, float* dv, long lddk, int B, int H, int N, int head_dim,
-                                float scale, hipStream_t stream) {
+                                const float* lse2, const float* delta, void* dk, void* dv, long lddk, int B, int H, int N, int head_dim,
+                                float scale, int out_dtype, const float* rope_cos, const float* rope_sin, hipStream_t stream) {
   AttnArgs a;
   int rc = fill_bwd_args(a, q, ldq, k, ldk, v, ldv, dout, lddo, lse2, delta, B, H, N, head_dim, scale);
   if (rc) return rc;
-  if (lddk % 4 || !al16(dk) || !al16(dv)) return OSUF_EINVAL;
-  a.dk = dk; a.dv = dv; a.lddk = lddk;
+  if (lddk % 8 || !al16(dk) || !al16(dv) || (out_dtype != OSUF_DT_F32 && out_dtype != OSUF_DT_BF16) ||
+      ((rope_cos == nullptr) != (rope_sin == nullptr)))
+    return OSUF_EINVAL;
+  a.dk = dk; a.dv = dv; a.lddk = lddk; a.g_bf16 = out_dtype == OSUF_DT_BF16; a.rcos = rope_cos; a.rsin = rope_sin;
   const int b8 = (B + 7) / 8 * 8;
   if (attn_waves() == 4) hipLaunchKernelGGL(mqa_bwd_dkv_kernel<4>, dim3(((N + 127) / 128) * b8), dim3(256), 2 * (4096 + 4096 + 256), stream, a);
   else {

@@ -280,18 +280,21 @@ def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.
     return o, lse
 
 
-def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, D: int, scale: float) -> torch.Tensor:
-    """Returns fp32 grads laid out like qkv: [B*N][(H+2)*D]."""
+def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, D: int, scale: float,
+            out_dtype: torch.dtype = torch.float32, cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Gradients laid out like qkv, [B*N][(H+2)*D], in out_dtype.  With the RoPE tables (N, D/2) the q / k gradients are those of
+    the un-rotated projections (the rotation's transpose is applied in the kernels' epilogues)."""
     M, W, ld = _rows(qkv)
     assert do.dtype == torch.bfloat16
-    dqkv = torch.empty((B, N, W), dtype=torch.float32, device=qkv.device)
+    dqkv = torch.empty((B, N, W), dtype=out_dtype, device=qkv.device)
     delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
-    base, gbase = qkv.data_ptr(), dqkv.data_ptr()
+    base, gbase, es = qkv.data_ptr(), dqkv.data_ptr(), dqkv.element_size()
     kp, vp, ldo_ = base + 2 * H * D, base + 2 * (H + 1) * D, _rows(do)[2]
     call("osuf_attn_delta", _p(do), ldo_, _p(o), _rows(o)[2], _DT[o.dtype], _p(delta), B, H, N, D, _stream())
-    call("osuf_mqa_bwd_dq", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase, W, B, H, N, D, scale, _stream(), meta=N)
-    call("osuf_mqa_bwd_dkv", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase + 4 * H * D, gbase + 4 * (H + 1) * D, W,
-         B, H, N, D, scale, _stream(), meta=N)
+    call("osuf_mqa_bwd_dq", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase, W, B, H, N, D, scale, _DT[out_dtype],
+         _p(cos), _p(sin), _stream(), meta=N)
+    call("osuf_mqa_bwd_dkv", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase + es * H * D, gbase + es * (H + 1) * D, W,
+         B, H, N, D, scale, _DT[out_dtype], _p(cos), _p(sin), _stream(), meta=N)
     return dqkv
 
 

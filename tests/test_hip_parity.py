@@ -284,6 +284,12 @@ def test_mqa_flash_vs_sdpa(N):
     dqkv = ops.mqa_bwd(qkv, o, do.to(DEV), lse, B, N, H, D, D ** -0.5)
     assert rell2(dqkv, qkv32.grad) < 1e-2
     assert relmax(dqkv, qkv32.grad) < 3e-2
+    # fused epilogue: transpose of the RoPE rotation on dq / dk (not dv) + cast == the stand-alone rope_bwd kernel on the fp32 result
+    cos, sin = Fn.rope_tables(N, D, 2 * N, DEV)
+    for out_dt in (torch.float32, torch.bfloat16):
+        ref_r = ops.rope_bwd(dqkv, out_dt, cos, sin, N, H + 1, H + 2, D)
+        got_r = ops.mqa_bwd(qkv, o, do.to(DEV), lse, B, N, H, D, D ** -0.5, out_dt, cos, sin)
+        assert got_r.dtype == out_dt and relmax(got_r.float(), ref_r.float()) < (1e-5 if out_dt == torch.float32 else 8e-3)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 3e-2)])
