@@ -376,9 +376,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
 static constexpr int kBig = 256;
 static constexpr int kBigStage = 2 * kBig * 128;        // 64 KiB: A 256 rows + B 256 rows, 128 B of K each
 
-template <typename T>
-__device__ __forceinline__ void gemm_big_epilogue(const GemmArgs& g, f32x16 (&acc)[4][2], char* smem, int m0, int n0, int tid, int lane, int wave,
-                                                  int wr, int wc) {
+// LOADS = false is the instantiation for launches without a residual (R) or an activation-derivative operand (U): its store loop
+// contains no vector-memory LOAD.  With a load anywhere in the loop body hipcc places `s_waitcnt vmcnt(0)` in front of every pass
+// (a pending load's destination registers are reused), and since stores count in vmcnt too, every pass then waited for the
+// previous pass's global stores to be acknowledged: ~0.3 us x 32 passes = the 10 us per-tile "fixed cost" of the round-1 triage
+// (found with per-phase triage builds of this function: no stores / no LDS transpose / no epilogue).  Preloading R / U per half
+// into registers and fully unrolling the passes was also tried: slower than this plain split (code size).
+template <typename T, bool LOADS>
+__device__ __forceinline__ void gemm_big_epilogue_impl(const GemmArgs& g, f32x16 (&acc)[4][2], char* smem, int m0, int n0, int tid, int lane,
+                                                       int wave, int wr, int wc) {
   const int lr = lane & 31, lh = lane >> 5;
   // ---- epilogue: per wave, two passes of a 64x64 fp32 sub-tile through its private 16 KiB LDS slice --------
   float* cs = reinterpret_cast<float*>(smem + wave * 16384);
@@ -386,13 +392,13 @@ __device__ __forceinline__ void gemm_big_epilogue(const GemmArgs& g, f32x16 (&ac
   int sb0 = 0;
   if (g.stats) {
     sb0 = m0 / g.rm.Lout;
-    if (tid < 2 * 66) sstat[tid] = 0.f;
+    for (int i = tid; i < 2 * 258; i += 512) sstat[i] = 0.f;      // a 256-row tile spans at most 257 samples
     __syncthreads();
   }
   T* C = reinterpret_cast<T*>(g.C);
   T* C2 = reinterpret_cast<T*>(g.C2);
-  const T* R = reinterpret_cast<const T*>(g.R);
-  const T* U = reinterpret_cast<const T*>(g.U);
+  const T* R = LOADS ? reinterpret_cast<const T*>(g.R) : nullptr;
+  const T* U = LOADS ? reinterpret_cast<const T*>(g.U) : nullptr;
   const int col4 = (lane & 15) * 4;                       // 16 lanes per 64-column row, 4 rows per pass
   const int n = n0 + wc * 64 + col4;
   const bool nok = n < g.N;
@@ -411,12 +417,27 @@ __device__ __forceinline__ void gemm_big_epilogue(const GemmArgs& g, f32x16 (&ac
         }
     __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): this wave's own LDS writes have landed
     __builtin_amdgcn_wave_barrier();
+    // sample index of this lane's row, carried across the passes (+4 rows each) instead of one integer division per pass
+    int bidx = 0, bpos = 0;
+    if (g.stats != nullptr || g.rscale != nullptr) {
+      const int mfirst = m0 + wr * 128 + half * 64 + (lane >> 4);
+      bidx = mfirst / g.rm.Lout;
+      bpos = mfirst - bidx * g.rm.Lout;
+    }
+    // GroupNorm statistics: per-lane running sums, reduced over the 16 lanes of a row and added to the tile's LDS slot only when
+    // the row's sample changes (and once at the end of the half) -- with L >= 64 that is one reduction per half instead of 16
+    float s1 = 0.f, s2 = 0.f;
+    int sslot = bidx - sb0;
+    auto flush_stats = [&]() {
+      const float t1 = group_sum<16>(s1), t2 = group_sum<16>(s2);
+      if ((lane & 15) == 0 && (t1 != 0.f || t2 != 0.f)) { atomicAdd(&sstat[2 * sslot], t1); atomicAdd(&sstat[2 * sslot + 1], t2); }
+      s1 = 0.f; s2 = 0.f;
+    };
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
       const int row = it * 4 + (lane >> 4);
       const int m = m0 + wr * 128 + half * 64 + row;
-      float s1 = 0.f, s2 = 0.f;
-      int bidx = 0;
+      if (g.stats && bidx - sb0 != sslot) { flush_stats(); sslot = bidx - sb0; }
       if (m < g.M && nok) {
         f32x4 a4 = *reinterpret_cast<const f32x4*>(cs + row * 64 + col4);
         float v[4] = {a4[0] + bias4[0], a4[1] + bias4[1], a4[2] + bias4[2], a4[3] + bias4[3]};
@@ -434,7 +455,6 @@ __device__ __forceinline__ void gemm_big_epilogue(const GemmArgs& g, f32x16 (&ac
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= silu_grad_f(u[e]);
         }
-        bidx = m / g.rm.Lout;
         if (R) {
           float rr[4];
           load4(R + (long)m * g.ldr + n, rr);
@@ -453,28 +473,28 @@ __device__ __forceinline__ void gemm_big_epilogue(const GemmArgs& g, f32x16 (&ac
           for (int e = 0; e < 4; ++e) { float q = ElemTraits<T>::rnd(v[e]); s1 += q; s2 += q * q; }
         }
       }
-      if (g.stats) {
-        s1 = group_sum<16>(s1);
-        s2 = group_sum<16>(s2);
-        if ((lane & 15) == 0 && m < g.M) {
-          int slot = bidx - sb0;
-          if (slot < 66) { atomicAdd(&sstat[2 * slot], s1); atomicAdd(&sstat[2 * slot + 1], s2); }
-          else { atomic_add_f64(g.stats + 2 * (long)bidx, (double)s1); atomic_add_f64(g.stats + 2 * (long)bidx + 1, (double)s2); }
-        }
-      }
+      bpos += 4;
+      while (bpos >= g.rm.Lout) { bpos -= g.rm.Lout; ++bidx; }
     }
+    if (g.stats) flush_stats();                             // slot < 258 by construction: no global atomic near the store loop
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
   }
   if (g.stats) {
     __syncthreads();
-    if (tid < 2 * 66) {
-      int slot = tid >> 1;
-      long b = sb0 + slot;
-      float v = sstat[tid];
-      if (v != 0.f && b * g.rm.Lout < g.M) atomic_add_f64(g.stats + 2 * b + (tid & 1), (double)v);
+    for (int i = tid; i < 2 * 258; i += 512) {
+      const long b = sb0 + (i >> 1);
+      const float v = sstat[i];
+      if (v != 0.f && b * g.rm.Lout < g.M) atomic_add_f64(g.stats + 2 * b + (i & 1), (double)v);
     }
   }
+}
+
+template <typename T>
+__device__ __forceinline__ void gemm_big_epilogue(const GemmArgs& g, f32x16 (&acc)[4][2], char* smem, int m0, int n0, int tid, int lane, int wave,
+                                                  int wr, int wc) {
+  if (g.R == nullptr && g.U == nullptr) gemm_big_epilogue_impl<T, false>(g, acc, smem, m0, n0, tid, lane, wave, wr, wc);
+  else gemm_big_epilogue_impl<T, true>(g, acc, smem, m0, n0, tid, lane, wave, wr, wc);
 }
 
 // DBG (bottleneck triage builds, selected by OSUF_GEMM_DBG; results are garbage unless 0): 1 = no MFMA, 2 = no LDS fragment
@@ -1092,7 +1112,7 @@ extern "C" int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, l
   const long big_tiles = (long)((M + kBig - 1) / kBig) * ((N + kBig - 1) / kBig);
   const bool use_big = !regstage && dtype == OSUF_DT_BF16 && min_tiles > 0 && big_tiles >= min_tiles && (N >= 192 || bigenv);
   if (use_big) {
-    const int lds_big = 2 * kBigStage + 1024;
+    const int lds_big = 2 * kBigStage + 2112;          // ring + per-tile GroupNorm stat slots (2 x 258 floats)
     static bool big_attr = false;
     if (!big_attr) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);

@@ -196,7 +196,11 @@ def test_big_tile_gemm_kernel(monkeypatch, kind, k, L):
         outs.append((y.float(), pre.float(), stats.clone(), dx.float(), dw.float()))
     monkeypatch.delenv("OSUF_GEMM_BIG_MIN_TILES")
     (y0, p0, s0, d0, w0), (y1, p1, s1, d1, w1) = outs
-    assert torch.equal(y0, y1) and torch.equal(p0, p1) and torch.equal(d0, d1)
+    assert torch.equal(p0, p1)
+    # y = silu(.)+res*rscale: the two kernels' epilogues are separate instantiations and may contract mul+add differently -- at most a
+    # bf16 ulp on a handful of elements; d (the input gradient computed FROM y) inherits that
+    for u, v in ((y0, y1), (d0, d1)):
+        assert torch.allclose(u, v, rtol=2.0 ** -7, atol=1e-3) and (u != v).float().mean().item() < 1e-3
     assert torch.allclose(s0, s1, rtol=1e-6)
     assert relmax(w1, w0) < 1e-5                                 # fp32 atomics: same products, different summation order
     xq, wq = x.float(), w.to(torch.bfloat16).float()
