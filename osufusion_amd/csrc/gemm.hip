@@ -382,7 +382,7 @@ static constexpr int kBigStage = 2 * kBig * 128;        // 64 KiB: A 256 rows + 
 // previous pass's global stores to be acknowledged: ~0.3 us x 32 passes = the 10 us per-tile "fixed cost" of the round-1 triage
 // (found with per-phase triage builds of this function: no stores / no LDS transpose / no epilogue).  Preloading R / U per half
 // into registers and fully unrolling the passes was also tried: slower than this plain split (code size).
-template <typename T, bool LOADS>
+template <typename T, int MODE>          // 0: no R / U;  1: R only, 2: U only (operand preloaded per half);  3: both (loads inside the passes)
 __device__ __forceinline__ void gemm_big_epilogue_impl(const GemmArgs& g, f32x16 (&acc)[4][2], char* smem, int m0, int n0, int tid, int lane,
                                                        int wave, int wr, int wc) {
   const int lr = lane & 31, lh = lane >> 5;
@@ -397,8 +397,8 @@ __device__ __forceinline__ void gemm_big_epilogue_impl(const GemmArgs& g, f32x16
   }
   T* C = reinterpret_cast<T*>(g.C);
   T* C2 = reinterpret_cast<T*>(g.C2);
-  const T* R = LOADS ? reinterpret_cast<const T*>(g.R) : nullptr;
-  const T* U = LOADS ? reinterpret_cast<const T*>(g.U) : nullptr;
+  const T* R = (MODE & 1) ? reinterpret_cast<const T*>(g.R) : nullptr;
+  const T* U = (MODE & 2) ? reinterpret_cast<const T*>(g.U) : nullptr;
   const int col4 = (lane & 15) * 4;                       // 16 lanes per 64-column row, 4 rows per pass
   const int n = n0 + wc * 64 + col4;
   const bool nok = n < g.N;
@@ -406,6 +406,29 @@ __device__ __forceinline__ void gemm_big_epilogue_impl(const GemmArgs& g, f32x16
   if (g.bias && nok) { f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n); bias4[0] = b[0]; bias4[1] = b[1]; bias4[2] = b[2]; bias4[3] = b[3]; }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
+    // MODE 1 / 2: this lane's 16 x 4 residual (or dact) values of the half, fetched before the passes so that the pass loop holds
+    // no vector-memory load (their latency hides behind the LDS transpose below)
+    // (kept as raw bits: converting inside the guarded block would put a wait behind every single load)
+    typedef __attribute__((ext_vector_type(sizeof(T) == 2 ? 2 : 4))) uint32_t raw4_t;
+    raw4_t pre[16];
+    if constexpr (MODE == 1 || MODE == 2) {
+      const T* P = MODE == 1 ? R : U;
+      const long ldp = MODE == 1 ? g.ldr : g.ldu;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int m = m0 + wr * 128 + half * 64 + it * 4 + (lane >> 4);
+        pre[it] = raw4_t{};
+        if (m < g.M && nok) pre[it] = *reinterpret_cast<const raw4_t*>(P + (long)m * ldp + n);
+      }
+    }
+    auto unpack = [&](const raw4_t& rw, float (&f)[4]) {
+      if constexpr (sizeof(T) == 2) {
+        f[0] = __uint_as_float(rw[0] << 16); f[1] = __uint_as_float(rw[0] & 0xFFFF0000u);
+        f[2] = __uint_as_float(rw[1] << 16); f[3] = __uint_as_float(rw[1] & 0xFFFF0000u);
+      } else {
+        f[0] = __uint_as_float(rw[0]); f[1] = __uint_as_float(rw[1]); f[2] = __uint_as_float(rw[2]); f[3] = __uint_as_float(rw[3]);
+      }
+    };
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -433,7 +456,7 @@ __device__ __forceinline__ void gemm_big_epilogue_impl(const GemmArgs& g, f32x16
       if ((lane & 15) == 0 && (t1 != 0.f || t2 != 0.f)) { atomicAdd(&sstat[2 * sslot], t1); atomicAdd(&sstat[2 * sslot + 1], t2); }
       s1 = 0.f; s2 = 0.f;
     };
-#pragma unroll 4
+#pragma unroll(MODE == 1 || MODE == 2 ? 16 : 4)
     for (int it = 0; it < 16; ++it) {
       const int row = it * 4 + (lane >> 4);
       const int m = m0 + wr * 128 + half * 64 + row;
@@ -451,13 +474,15 @@ __device__ __forceinline__ void gemm_big_epilogue_impl(const GemmArgs& g, f32x16
         }
         if (U) {
           float u[4];
-          load4(U + (long)m * g.ldu + n, u);
+          if constexpr (MODE == 2) unpack(pre[it], u);
+          else load4(U + (long)m * g.ldu + n, u);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= silu_grad_f(u[e]);
         }
         if (R) {
           float rr[4];
-          load4(R + (long)m * g.ldr + n, rr);
+          if constexpr (MODE == 1) unpack(pre[it], rr);
+          else load4(R + (long)m * g.ldr + n, rr);
           if (g.rscale) {
             f32x4 sc = *reinterpret_cast<const f32x4*>(g.rscale + (long)bidx * g.N + n);
 #pragma unroll
@@ -493,8 +518,10 @@ __device__ __forceinline__ void gemm_big_epilogue_impl(const GemmArgs& g, f32x16
 template <typename T>
 __device__ __forceinline__ void gemm_big_epilogue(const GemmArgs& g, f32x16 (&acc)[4][2], char* smem, int m0, int n0, int tid, int lane, int wave,
                                                   int wr, int wc) {
-  if (g.R == nullptr && g.U == nullptr) gemm_big_epilogue_impl<T, false>(g, acc, smem, m0, n0, tid, lane, wave, wr, wc);
-  else gemm_big_epilogue_impl<T, true>(g, acc, smem, m0, n0, tid, lane, wave, wr, wc);
+  if (g.R == nullptr && g.U == nullptr) gemm_big_epilogue_impl<T, 0>(g, acc, smem, m0, n0, tid, lane, wave, wr, wc);
+  else if (g.U == nullptr) gemm_big_epilogue_impl<T, 1>(g, acc, smem, m0, n0, tid, lane, wave, wr, wc);
+  else if (g.R == nullptr) gemm_big_epilogue_impl<T, 2>(g, acc, smem, m0, n0, tid, lane, wave, wr, wc);
+  else gemm_big_epilogue_impl<T, 3>(g, acc, smem, m0, n0, tid, lane, wave, wr, wc);
 }
 
 // DBG (bottleneck triage builds, selected by OSUF_GEMM_DBG; results are garbage unless 0): 1 = no MFMA, 2 = no LDS fragment
