@@ -1012,20 +1012,29 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(WgradArgs g) {
 // deterministic second stage of the split wgrad: dW (+)= sum_s ws[s][t][i], i = n1*N2 + n2.
 // LAYOUT 0: dW[t][i] (the kernel's own order)   LAYOUT 1: dW[i][t] = torch's (Cout, Cin, k) conv weight layout -- the permute
 // is free here: a thread owns one i and writes its `taps` values contiguously.
+// sum of `splits` partial float4s that lie `stride` floats apart; four independent chains so that four loads are in flight per
+// lane (a single dependent chain waits out one L2 / HBM round trip per split)
+__device__ __forceinline__ f32x4 sum_partials(const float* p, long stride, int splits) {
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  int sidx = 0;
+  for (; sidx + 4 <= splits; sidx += 4) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p + (long)sidx * stride);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p + (long)(sidx + 1) * stride);
+    const f32x4 b2 = *reinterpret_cast<const f32x4*>(p + (long)(sidx + 2) * stride);
+    const f32x4 b3 = *reinterpret_cast<const f32x4*>(p + (long)(sidx + 3) * stride);
+    a0 += b0; a1 += b1; a2 += b2; a3 += b3;
+  }
+  for (; sidx < splits; ++sidx) a0 += *reinterpret_cast<const f32x4*>(p + (long)sidx * stride);
+  return (a0 + a1) + (a2 + a3);
+}
+
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* dW, long n12, int taps, int splits, int accumulate) {
   if constexpr (LAYOUT == 0) {
     const long n = n12 * taps, n4 = n >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-      f32x4 a = reinterpret_cast<const f32x4*>(ws)[i];
-      for (int sidx = 1; sidx < splits; ++sidx) {
-        f32x4 b = reinterpret_cast<const f32x4*>(ws + (long)sidx * n)[i];
-        a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
-      }
-      if (accumulate) {
-        f32x4 d = reinterpret_cast<f32x4*>(dW)[i];
-        a[0] += d[0]; a[1] += d[1]; a[2] += d[2]; a[3] += d[3];
-      }
+      f32x4 a = sum_partials(ws + 4 * i, n, splits);
+      if (accumulate) a += reinterpret_cast<f32x4*>(dW)[i];
       reinterpret_cast<f32x4*>(dW)[i] = a;
     }
   } else {
@@ -1035,28 +1044,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, floa
       if (taps == 3) {                                     // k3 convs (all but the stems): 12 outputs = three 16-B stores
         f32x4 a[3];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          a[t] = reinterpret_cast<const f32x4*>(ws + (long)t * n12)[q];
-          for (int sidx = 1; sidx < splits; ++sidx) {
-            f32x4 b = reinterpret_cast<const f32x4*>(ws + (long)sidx * n + (long)t * n12)[q];
-            a[t][0] += b[0]; a[t][1] += b[1]; a[t][2] += b[2]; a[t][3] += b[3];
-          }
-        }
+        for (int t = 0; t < 3; ++t) a[t] = sum_partials(ws + (long)t * n12 + 4 * q, n, splits);
         f32x4* dst = reinterpret_cast<f32x4*>(dW + 12 * q);
         f32x4 o0 = {a[0][0], a[1][0], a[2][0], a[0][1]}, o1 = {a[1][1], a[2][1], a[0][2], a[1][2]}, o2 = {a[2][2], a[0][3], a[1][3], a[2][3]};
-        if (accumulate) {
-          f32x4 d0 = dst[0], d1 = dst[1], d2 = dst[2];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { o0[e] += d0[e]; o1[e] += d1[e]; o2[e] += d2[e]; }
-        }
+        if (accumulate) { o0 += dst[0]; o1 += dst[1]; o2 += dst[2]; }
         dst[0] = o0; dst[1] = o1; dst[2] = o2;
       } else {
         for (int t = 0; t < taps; ++t) {
-          f32x4 a = reinterpret_cast<const f32x4*>(ws + (long)t * n12)[q];
-          for (int sidx = 1; sidx < splits; ++sidx) {
-            f32x4 b = reinterpret_cast<const f32x4*>(ws + (long)sidx * n + (long)t * n12)[q];
-            a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
-          }
+          const f32x4 a = sum_partials(ws + (long)t * n12 + 4 * q, n, splits);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float* dst = dW + (4 * q + e) * taps + t;
