@@ -1074,7 +1074,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* Y, long ldy, int M
   const int m_end = min(M, m_begin + rows_per_block);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (n < N) {
-    for (int m = m_begin + rl; m < m_end; m += 8) {
+    int m = m_begin + rl;
+    for (; m + 24 < m_end; m += 32) {                  // four independent 16-B loads in flight per lane
+      float v0[8], v1[8], v2[8], v3[8];
+      load8(Y + (long)m * ldy + n, v0);
+      load8(Y + (long)(m + 8) * ldy + n, v1);
+      load8(Y + (long)(m + 16) * ldy + n, v2);
+      load8(Y + (long)(m + 24) * ldy + n, v3);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+    }
+    for (; m < m_end; m += 8) {
       float v[8];
       load8(Y + (long)m * ldy + n, v);
 #pragma unroll
@@ -1255,7 +1265,7 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
 
 extern "C" int osuf_colsum(int dtype, const void* Y, long ldy, int M, int N, float* out, hipStream_t stream) {
   if (M <= 0 || N <= 0 || N % 8 || ldy % 8 || !aligned16(Y)) return OSUF_EINVAL;
-  const int rows_per_block = 512;
+  const int rows_per_block = 256;
   dim3 grid((N + 255) / 256, (M + rows_per_block - 1) / rows_per_block);
   if (dtype == OSUF_DT_BF16) {
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)Y, ldy, M, N, out, rows_per_block);
