@@ -967,6 +967,11 @@ extern "C" int osuf_attn_delta(const void* dout, long lddo, const void* o, long 
 }
 
 // dq: [B*N][lddq] in out_dtype, head h at columns h*64; rope_cos / rope_sin ([N][32], or both NULL): store the gradient of the un-rotated q
+static int dq_pipe_min() {
+  static const int v = getenv("OSUF_ATTN_DQ_PIPE_MIN") ? atoi(getenv("OSUF_ATTN_DQ_PIPE_MIN")) : 2048;
+  return v;
+}
+
 extern "C" int osuf_mqa_bwd_dq(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
                                const float* lse2, const float* delta, void* dq, long lddq, int B, int H, int N, int head_dim, float scale,
                                int out_dtype, const float* rope_cos, const float* rope_sin, hipStream_t stream) {
@@ -978,8 +983,8 @@ extern "C" int osuf_mqa_bwd_dq(const void* q, long ldq, const void* k, long ldk,
   a.dq = dq; a.lddq = lddq; a.g_bf16 = out_dtype == OSUF_DT_BF16; a.rcos = rope_cos; a.rsin = rope_sin;
   const int nvb = ((N + 31) / 32) * H;
   if (attn_waves() == 4) hipLaunchKernelGGL(mqa_bwd_dq_kernel<4>, dim3((nvb + 3) / 4, B), dim3(256), 32768, stream, a);
-  // the pipelined kernel (2 waves/SIMD, 256 VGPRs) wins once the key loop is long: +4.5 % at N=4096, even at 2048, -3 % at <= 1024
-  else if (N < 3072 || getenv("OSUF_ATTN_NOPIPE")) hipLaunchKernelGGL(mqa_bwd_dq_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768, stream, a);
+  // the pipelined kernel (2 waves/SIMD, 256 VGPRs) wins once the key loop is long: +4.5 % at N=4096, +3 % at 2048, -2 % at <= 1024
+  else if (N < dq_pipe_min() || getenv("OSUF_ATTN_NOPIPE")) hipLaunchKernelGGL(mqa_bwd_dq_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768, stream, a);
   else {
     static bool once = ((void)hipFuncSetAttribute((const void*)mqa_bwd_dq_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), true);
     (void)once;
