@@ -386,7 +386,10 @@ template <typename T, int MODE>          // 0: no R / U;  1: R only, 2: U only (
 __device__ __forceinline__ void gemm_big_epilogue_impl(const GemmArgs& g, f32x16 (&acc)[4][2], char* smem, int m0, int n0, int tid, int lane,
                                                        int wave, int wr, int wc) {
   const int lr = lane & 31, lh = lane >> 5;
-  // ---- epilogue: per wave, two passes of a 64x64 fp32 sub-tile through its private 16 KiB LDS slice --------
+  // ---- epilogue: per wave, two halves of a 64x64 fp32 sub-tile through its private 16 KiB LDS slice; read back as 8 columns per
+  //      lane (8 lanes per row, 8 rows per pass, 8 passes per half) so that a bf16 row segment leaves as one 16-byte store.
+  //      LDS image: row-major [64][64] floats with the 16-B chunk index XORed by (row >> 1) & 1 -- that keeps both the
+  //      ds_write_b32 of the accumulators and the two ds_read_b128 per lane free of bank conflicts (lane groups of b128 mix 4 rows).
   float* cs = reinterpret_cast<float*>(smem + wave * 16384);
   float* sstat = reinterpret_cast<float*>(smem + 2 * kBigStage);
   int sb0 = 0;
@@ -399,106 +402,114 @@ __device__ __forceinline__ void gemm_big_epilogue_impl(const GemmArgs& g, f32x16
   T* C2 = reinterpret_cast<T*>(g.C2);
   const T* R = (MODE & 1) ? reinterpret_cast<const T*>(g.R) : nullptr;
   const T* U = (MODE & 2) ? reinterpret_cast<const T*>(g.U) : nullptr;
-  const int col4 = (lane & 15) * 4;                       // 16 lanes per 64-column row, 4 rows per pass
-  const int n = n0 + wc * 64 + col4;
-  const bool nok = n < g.N;
-  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-  if (g.bias && nok) { f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n); bias4[0] = b[0]; bias4[1] = b[1]; bias4[2] = b[2]; bias4[3] = b[3]; }
+  const int col8 = (lane & 7) * 8;
+  const int prow = lane >> 3;                              // row of this lane inside a pass
+  const int n = n0 + wc * 64 + col8;
+  const bool nok = n < g.N;                                // N % 8 == 0 (launcher)
+  float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (g.bias && nok) load8(g.bias + n, bias8);
+  const int rd0 = ((2 * (lane & 7)) ^ ((prow >> 1) & 1)) << 2;           // float offsets of this lane's two 16-B chunks in its row
+  const int rd1 = ((2 * (lane & 7) + 1) ^ ((prow >> 1) & 1)) << 2;
+  constexpr int RAWN = sizeof(T) == 2 ? 4 : 8;             // 8 elements of T as 32-bit words
+  typedef __attribute__((ext_vector_type(RAWN))) uint32_t raw8_t;
+  auto unpack = [&](const raw8_t& rw, float (&f)[8]) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(rw[i] << 16); f[2 * i + 1] = __uint_as_float(rw[i] & 0xFFFF0000u); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = __uint_as_float(rw[i]);
+    }
+  };
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    // MODE 1 / 2: this lane's 16 x 4 residual (or dact) values of the half, fetched before the passes so that the pass loop holds
-    // no vector-memory load (their latency hides behind the LDS transpose below)
-    // (kept as raw bits: converting inside the guarded block would put a wait behind every single load)
-    typedef __attribute__((ext_vector_type(sizeof(T) == 2 ? 2 : 4))) uint32_t raw4_t;
-    raw4_t pre[16];
+    // MODE 1 / 2: this lane's 8 x 8 residual (or dact) values of the half, fetched before the passes so that the pass loop holds
+    // no vector-memory load (kept as raw bits: converting inside the guarded block would put a wait behind every single load)
+    raw8_t pre[8];
     if constexpr (MODE == 1 || MODE == 2) {
       const T* P = MODE == 1 ? R : U;
       const long ldp = MODE == 1 ? g.ldr : g.ldu;
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int m = m0 + wr * 128 + half * 64 + it * 4 + (lane >> 4);
-        pre[it] = raw4_t{};
-        if (m < g.M && nok) pre[it] = *reinterpret_cast<const raw4_t*>(P + (long)m * ldp + n);
+      for (int it = 0; it < 8; ++it) {
+        const int m = m0 + wr * 128 + half * 64 + it * 8 + prow;
+        pre[it] = raw8_t{};
+        if (m < g.M && nok) pre[it] = *reinterpret_cast<const raw8_t*>(P + (long)m * ldp + n);
       }
     }
-    auto unpack = [&](const raw4_t& rw, float (&f)[4]) {
-      if constexpr (sizeof(T) == 2) {
-        f[0] = __uint_as_float(rw[0] << 16); f[1] = __uint_as_float(rw[0] & 0xFFFF0000u);
-        f[2] = __uint_as_float(rw[1] << 16); f[3] = __uint_as_float(rw[1] & 0xFFFF0000u);
-      } else {
-        f[0] = __uint_as_float(rw[0]); f[1] = __uint_as_float(rw[1]); f[2] = __uint_as_float(rw[2]); f[3] = __uint_as_float(rw[3]);
-      }
-    };
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          cs[row * 64 + j * 32 + lr] = acc[half * 2 + i][j][r];
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int col = j * 32 + lr;
+          cs[row * 64 + ((((col >> 2) ^ ((row >> 1) & 1)) << 2) | (col & 3))] = acc[half * 2 + i][j][r];
         }
     __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): this wave's own LDS writes have landed
     __builtin_amdgcn_wave_barrier();
-    // sample index of this lane's row, carried across the passes (+4 rows each) instead of one integer division per pass
+    // sample index of this lane's row, carried across the passes (+8 rows each) instead of one integer division per pass
     int bidx = 0, bpos = 0;
     if (g.stats != nullptr || g.rscale != nullptr) {
-      const int mfirst = m0 + wr * 128 + half * 64 + (lane >> 4);
+      const int mfirst = m0 + wr * 128 + half * 64 + prow;
       bidx = mfirst / g.rm.Lout;
       bpos = mfirst - bidx * g.rm.Lout;
     }
-    // GroupNorm statistics: per-lane running sums, reduced over the 16 lanes of a row and added to the tile's LDS slot only when
-    // the row's sample changes (and once at the end of the half) -- with L >= 64 that is one reduction per half instead of 16
+    // GroupNorm statistics: per-lane running sums, reduced over the 8 lanes of a row and added to the tile's LDS slot only when
+    // the row's sample changes (and once at the end of the half) -- with L >= 64 that is one reduction per half instead of 8
     float s1 = 0.f, s2 = 0.f;
     int sslot = bidx - sb0;
     auto flush_stats = [&]() {
-      const float t1 = group_sum<16>(s1), t2 = group_sum<16>(s2);
-      if ((lane & 15) == 0 && (t1 != 0.f || t2 != 0.f)) { atomicAdd(&sstat[2 * sslot], t1); atomicAdd(&sstat[2 * sslot + 1], t2); }
+      const float t1 = group_sum<8>(s1), t2 = group_sum<8>(s2);
+      if ((lane & 7) == 0 && (t1 != 0.f || t2 != 0.f)) { atomicAdd(&sstat[2 * sslot], t1); atomicAdd(&sstat[2 * sslot + 1], t2); }
       s1 = 0.f; s2 = 0.f;
     };
-#pragma unroll(MODE == 1 || MODE == 2 ? 16 : 4)
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 4 + (lane >> 4);
+#pragma unroll(MODE == 1 || MODE == 2 ? 8 : 4)
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + prow;
       const int m = m0 + wr * 128 + half * 64 + row;
       if (g.stats && bidx - sb0 != sslot) { flush_stats(); sslot = bidx - sb0; }
       if (m < g.M && nok) {
-        f32x4 a4 = *reinterpret_cast<const f32x4*>(cs + row * 64 + col4);
-        float v[4] = {a4[0] + bias4[0], a4[1] + bias4[1], a4[2] + bias4[2], a4[3] + bias4[3]};
-        if (C2) store4(C2 + (long)m * g.ldc2 + n, v);
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(cs + row * 64 + rd0);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(cs + row * 64 + rd1);
+        float v[8] = {a0[0] + bias8[0], a0[1] + bias8[1], a0[2] + bias8[2], a0[3] + bias8[3],
+                      a1[0] + bias8[4], a1[1] + bias8[5], a1[2] + bias8[6], a1[3] + bias8[7]};
+        if (C2) store8(C2 + (long)m * g.ldc2 + n, v);
         if (g.act == 1) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+          for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
         } else if (g.act == 2) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = sigmoid_f(v[e]);
+          for (int e = 0; e < 8; ++e) v[e] = sigmoid_f(v[e]);
         }
         if (U) {
-          float u[4];
+          float u[8];
           if constexpr (MODE == 2) unpack(pre[it], u);
-          else load4(U + (long)m * g.ldu + n, u);
+          else load8(U + (long)m * g.ldu + n, u);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= silu_grad_f(u[e]);
+          for (int e = 0; e < 8; ++e) v[e] *= silu_grad_f(u[e]);
         }
         if (R) {
-          float rr[4];
+          float rr[8];
           if constexpr (MODE == 1) unpack(pre[it], rr);
-          else load4(R + (long)m * g.ldr + n, rr);
+          else load8(R + (long)m * g.ldr + n, rr);
           if (g.rscale) {
-            f32x4 sc = *reinterpret_cast<const f32x4*>(g.rscale + (long)bidx * g.N + n);
+            float sc[8];
+            load8(g.rscale + (long)bidx * g.N + n, sc);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += rr[e] * sc[e];
+            for (int e = 0; e < 8; ++e) v[e] += rr[e] * sc[e];
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += rr[e];
+            for (int e = 0; e < 8; ++e) v[e] += rr[e];
           }
         }
-        store4(C + (long)m * g.ldc + n, v);
+        store8(C + (long)m * g.ldc + n, v);
         if (g.stats) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { float q = ElemTraits<T>::rnd(v[e]); s1 += q; s2 += q * q; }
+          for (int e = 0; e < 8; ++e) { float q = ElemTraits<T>::rnd(v[e]); s1 += q; s2 += q * q; }
         }
       }
-      bpos += 4;
+      bpos += 8;
       while (bpos >= g.rm.Lout) { bpos -= g.rm.Lout; ++bidx; }
     }
     if (g.stats) flush_stats();                             // slot < 258 by construction: no global atomic near the store loop
@@ -1142,7 +1153,9 @@ extern "C" int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, l
   const char* bigenv = getenv("OSUF_GEMM_BIG_MIN_TILES");
   const long min_tiles = bigenv ? atol(bigenv) : 192;
   const long big_tiles = (long)((M + kBig - 1) / kBig) * ((N + kBig - 1) / kBig);
-  const bool use_big = !regstage && dtype == OSUF_DT_BF16 && min_tiles > 0 && big_tiles >= min_tiles && (N >= 192 || bigenv);
+  const bool use_big = !regstage && dtype == OSUF_DT_BF16 && min_tiles > 0 && big_tiles >= min_tiles && (N >= 192 || bigenv) && N % 8 == 0 &&
+                       ldc % 8 == 0 && (!C2 || ldc2 % 8 == 0) && (!R || ldr % 8 == 0) && (!U || ldu % 8 == 0) &&
+                       (!bias || (reinterpret_cast<uintptr_t>(bias) & 31) == 0) && (!rscale || (reinterpret_cast<uintptr_t>(rscale) & 31) == 0);
   if (use_big) {
     const int lds_big = 2 * kBigStage + 2112;          // ring + per-tile GroupNorm stat slots (2 x 258 floats)
     static bool big_attr = false;
