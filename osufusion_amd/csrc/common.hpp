@@ -92,8 +92,10 @@ __device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
   *reinterpret_cast<f32x4*>(p) = a;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_rcp_f32 (<= 1 ulp) instead of an IEEE division: the division expands to ~10 VALU ops per element (v_div_scale / v_div_fmas /
+// v_div_fixup + Newton steps), and the GroupNorm / SiLU kernels evaluate it for every element of every activation
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 // d/dx silu(x) = s * (1 + x * (1 - s)), s = sigmoid(x)
 __device__ __forceinline__ float silu_grad_f(float x) {
   float s = sigmoid_f(x);
