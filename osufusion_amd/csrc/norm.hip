@@ -7,6 +7,16 @@
 // wave64 xor-shuffle reductions).  All loads/stores are 16 B per lane.
 #include "common.hpp"
 
+struct ColGeom {
+  int cp, rp;          // chunk lanes, row lanes (cp * rp <= 256)
+};
+__device__ __forceinline__ ColGeom col_geom(int chunks) {
+  ColGeom g;
+  g.cp = chunks;
+  g.rp = 256 / chunks;
+  return g;
+}
+
 static constexpr float kEps = 1e-5f;
 
 // ------------------------------------------------------------------------------------------------
@@ -26,41 +36,45 @@ __global__ void gn_finalize_kernel(const double* stats, float* mr, int B, double
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const T* y, long ldy, T* h, long ldh, const float* mr,
                                                            const float* gamma, const float* beta, const float* ss,
-                                                           int M, int C, int L) {
+                                                           int M, int C, int L, int rows_per_block) {
+  // grid (row blocks of one sample, sample): a thread keeps ONE 8-channel chunk and walks rows, so gamma / beta / scale / shift /
+  // mean / rstd are loaded once per thread and no index division runs per element (the flat idx / chunks, m / L form spent more
+  // VALU on 64-bit divisions and operand reloads than on the normalisation itself)
   const int chunks = C >> 3;
-  const long total = (long)M * chunks;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int m = (int)(idx / chunks), c = (int)(idx - (long)m * chunks) * 8;
-    const int b = m / L;
-    const float mean = mr[2 * b], rstd = mr[2 * b + 1];
-    float v[8], g[8], bt[8];
-    load8(y + (long)m * ldy + c, v);
-    load8(gamma + c, g);
-    load8(beta + c, bt);
-    if (ss) {
-      float sc[8], sh[8];
-      load8(ss + (long)b * 2 * C + c, sc);
-      load8(ss + (long)b * 2 * C + C + c, sh);
+  const int b = blockIdx.y;
+  const ColGeom cg = col_geom(chunks);
+  const int ch = threadIdx.x % cg.cp, rl = threadIdx.x / cg.cp;
+  if (rl >= cg.rp) return;
+  const int c = ch * 8;
+  const float mean = mr[2 * b], rstd = mr[2 * b + 1];
+  float g[8], bt[8], k[8], sh[8];
+  load8(gamma + c, g);
+  load8(beta + c, bt);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = silu_f(((v[e] - mean) * rstd * g[e] + bt[e]) * (1.f + sc[e]) + sh[e]);
-    } else {
+  for (int e = 0; e < 8; ++e) { k[e] = 1.f; sh[e] = 0.f; }
+  if (ss) {
+    float sc[8];
+    load8(ss + (long)b * 2 * C + c, sc);
+    load8(ss + (long)b * 2 * C + C + c, sh);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = silu_f((v[e] - mean) * rstd * g[e] + bt[e]);
-    }
-    store8(h + (long)m * ldh + c, v);
+    for (int e = 0; e < 8; ++e) k[e] = 1.f + sc[e];
+  }
+  // out = silu(((v - mean) * rstd * g + bt) * k + sh) = silu(v * A + Bc)
+  float A[8], Bc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { A[e] = rstd * g[e] * k[e]; Bc[e] = (bt[e] - mean * rstd * g[e]) * k[e] + sh[e]; }
+  const int n_end = min(L, (int)(blockIdx.x + 1) * rows_per_block);
+  for (int n = blockIdx.x * rows_per_block + rl; n < n_end; n += cg.rp) {
+    const long m = (long)b * L + n;
+    float v[8];
+    load8(y + m * ldy + c, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = silu_f(fmaf(v[e], A[e], Bc[e]));
+    store8(h + m * ldh + c, v);
   }
 }
 
 // column-reduce geometry shared by several kernels
-struct ColGeom {
-  int cp, rp;          // chunk lanes, row lanes (cp * rp <= 256)
-};
-__device__ __forceinline__ ColGeom col_geom(int chunks) {
-  ColGeom g;
-  g.cp = chunks;
-  g.rp = 256 / chunks;
-  return g;
-}
 
 // T1[b][c] = sum_n du * xhat, T2[b][c] = sum_n du   with du = dh * silu'(u)
 template <typename T>
@@ -159,35 +173,45 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* T12, 
   }
 }
 
-// dy = rstd * ( gamma*(1+scale)*du - S1/cnt - xhat*S2/cnt )
+// dy = rstd * ( gamma*(1+scale)*du - S1/cnt - xhat*S2/cnt )        same (row block, sample) grid as the forward apply
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* dh, long lddh, const T* y, long ldy, T* dy, long lddy,
                                                            const float* mr, const float* gamma, const float* beta, const float* ss,
-                                                           const float* S, int M, int C, int L, float inv_count) {
+                                                           const float* S, int M, int C, int L, float inv_count, int rows_per_block) {
   const int chunks = C >> 3;
-  const long total = (long)M * chunks;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int m = (int)(idx / chunks), c = (int)(idx - (long)m * chunks) * 8;
-    const int b = m / L;
-    const float mean = mr[2 * b], rstd = mr[2 * b + 1];
-    const float a1 = S[2 * b] * inv_count, a2 = S[2 * b + 1] * inv_count;
-    float v[8], d[8], g[8], bt[8], sc[8], sh[8];
-    load8(y + (long)m * ldy + c, v);
-    load8(dh + (long)m * lddh + c, d);
-    load8(gamma + c, g);
-    load8(beta + c, bt);
+  const int b = blockIdx.y;
+  const ColGeom cg = col_geom(chunks);
+  const int ch = threadIdx.x % cg.cp, rl = threadIdx.x / cg.cp;
+  if (rl >= cg.rp) return;
+  const int c = ch * 8;
+  const float mean = mr[2 * b], rstd = mr[2 * b + 1];
+  const float a1 = S[2 * b] * inv_count, a2 = S[2 * b + 1] * inv_count;
+  float g[8], bt[8], k[8], sh[8];
+  load8(gamma + c, g);
+  load8(beta + c, bt);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = 0.f; sh[e] = 0.f; }
-    if (ss) { load8(ss + (long)b * 2 * C + c, sc); load8(ss + (long)b * 2 * C + C + c, sh); }
+  for (int e = 0; e < 8; ++e) { k[e] = 1.f; sh[e] = 0.f; }
+  if (ss) {
+    float sc[8];
+    load8(ss + (long)b * 2 * C + c, sc);
+    load8(ss + (long)b * 2 * C + C + c, sh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) k[e] = 1.f + sc[e];
+  }
+  const int n_end = min(L, (int)(blockIdx.x + 1) * rows_per_block);
+  for (int n = blockIdx.x * rows_per_block + rl; n < n_end; n += cg.rp) {
+    const long m = (long)b * L + n;
+    float v[8], d[8];
+    load8(y + m * ldy + c, v);
+    load8(dh + m * lddh + c, d);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float xh = (v[e] - mean) * rstd;
-      float k = 1.f + sc[e];
-      float u = (xh * g[e] + bt[e]) * k + sh[e];
-      float du = d[e] * silu_grad_f(u);
-      v[e] = rstd * (g[e] * k * du - a1 - xh * a2);
+      const float xh = (v[e] - mean) * rstd;
+      const float u = (xh * g[e] + bt[e]) * k[e] + sh[e];
+      const float du = d[e] * silu_grad_f(u);
+      v[e] = rstd * (g[e] * k[e] * du - a1 - xh * a2);
     }
-    store8(dy + (long)m * lddy + c, v);
+    store8(dy + m * lddy + c, v);
   }
 }
 
@@ -548,8 +572,12 @@ extern "C" int osuf_gn_finalize(const double* stats, float* mr, int B, long coun
 extern "C" int osuf_gn_apply_fwd(int dtype, const void* y, long ldy, void* h, long ldh, const float* mr, const float* gamma,
                                  const float* beta, const float* ss, int M, int C, int L, hipStream_t stream) {
   if (bad_c(C) || M <= 0 || L <= 0 || M % L || ldy % 8 || ldh % 8) return OSUF_EINVAL;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(gn_apply_fwd_kernel<T>, dim3(ew_grid((long)M * (C / 8))), dim3(256), 0, stream,
-                                       (const T*)y, ldy, (T*)h, ldh, mr, gamma, beta, ss, M, C, L));
+  {
+    const int rp = 256 / (C / 8);
+    const int rpb = rp * 8;                                // 8 rows per thread
+    DISPATCH_T(dtype, hipLaunchKernelGGL(gn_apply_fwd_kernel<T>, dim3((L + rpb - 1) / rpb, M / L), dim3(256), 0, stream,
+                                         (const T*)y, ldy, (T*)h, ldh, mr, gamma, beta, ss, M, C, L, rpb));
+  }
   return osuf_launch_status();
 }
 
@@ -570,8 +598,11 @@ extern "C" int osuf_gn_bwd(int dtype, const void* dh, long lddh, const void* y, 
                                        stream, (const T*)dh, lddh, (const T*)y, ldy, mr, gamma, beta, ss, T123, C, L, rows_per_block));
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, stream, T123, gamma, beta, ss, S, dss, dgamma, dbeta, dbias, dyy, mr,
                      C, L, inv_count);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(ew_grid((long)M * chunks)), dim3(256), 0, stream, (const T*)dh,
-                                       lddh, (const T*)y, ldy, (T*)dy, lddy, mr, gamma, beta, ss, S, M, C, L, inv_count));
+  {
+    const int rpb = rp * 8;                                // 8 rows per thread
+    DISPATCH_T(dtype, hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3((L + rpb - 1) / rpb, B), dim3(256), 0, stream, (const T*)dh,
+                                         lddh, (const T*)y, ldy, (T*)dy, lddy, mr, gamma, beta, ss, S, M, C, L, inv_count, rpb));
+  }
   return osuf_launch_status();
 }
 
