@@ -56,8 +56,10 @@ static constexpr int kStageBytes = 2 * kTile * 128;   // A tile + B tile, 128 B 
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <typename T>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], char* smem, int m0, int n0, int tid, int lane, int wr, int wc) {
+// LOADS = false: instantiation for launches without residual / dact operand -- no vector-memory load inside the store loop, hence no
+// `s_waitcnt vmcnt(0)` (which also waits for the previous pass's stores) in front of every pass; see gemm_big_epilogue_impl.
+template <typename T, bool LOADS>
+__device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&acc)[2][2], char* smem, int m0, int n0, int tid, int lane, int wr, int wc) {
   const int lr = lane & 31, lh = lane >> 5;
   // ---- epilogue: accumulators -> LDS (fp32 [128][128]) -> coalesced row stores -------------------------
   float* cs = reinterpret_cast<float*>(smem);
@@ -81,8 +83,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
 
   T* C = reinterpret_cast<T*>(g.C);
   T* C2 = reinterpret_cast<T*>(g.C2);
-  const T* R = reinterpret_cast<const T*>(g.R);
-  const T* U = reinterpret_cast<const T*>(g.U);
+  const T* R = LOADS ? reinterpret_cast<const T*>(g.R) : nullptr;
+  const T* U = LOADS ? reinterpret_cast<const T*>(g.U) : nullptr;
   const int col4 = (tid & 31) * 4;
   const int n = n0 + col4;
   const bool nok = n < g.N;        // N % 4 == 0 is required by the host wrapper
@@ -149,6 +151,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2
       if (v != 0.f && b * g.rm.Lout < g.M) atomic_add_f64(g.stats + 2 * b + (tid & 1), (double)v);
     }
   }
+}
+
+template <typename T>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], char* smem, int m0, int n0, int tid, int lane, int wr, int wc) {
+  if (g.R == nullptr && g.U == nullptr) gemm_epilogue_impl<T, false>(g, acc, smem, m0, n0, tid, lane, wr, wc);
+  else gemm_epilogue_impl<T, true>(g, acc, smem, m0, n0, tid, lane, wr, wc);
 }
 
 template <typename T>
