@@ -694,6 +694,122 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Skinny-N variant (N <= 32: the rank-r LoRA products u = A(x) and du = dy (s g B), functional.adapter_grads): a 256 x 32 tile per
+// workgroup -- 8 waves x one 32x32 MFMA tile -- so the DMA traffic is the A panel only (the 128 / 256-wide tiles spend 4-8x the
+// MFMAs and B-side DMA slots on zero columns).  Same loader (per-tap row maps, incremental pointers), 2 x 36 KiB ring -> two
+// workgroups per CU.  No epilogue options: C = A W^T in the storage type.
+// ---------------------------------------------------------------------------------------------------------
+static constexpr int kSkStage = kBig * 128 + 32 * 128;    // A 256 rows + B 32 rows, 128 B of K each
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_skinny_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  constexpr int BK = 64, EPC = 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * kBig;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  int a_base[4], a_pos[4], koff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    koff[i] = ((lane & 7) ^ ((row >> 1) & 7)) * EPC;
+    const int m = m0 + row;
+    if (m < g.M) { int b = m / g.rm.Lout; a_base[i] = b * g.rm.Lin; a_pos[i] = m - b * g.rm.Lout; }
+    else { a_base[i] = 0; a_pos[i] = -1; }
+  }
+  // B loader: waves 0-3, one instruction each (8 rows); its swizzle follows the B tile's own row index
+  const int brow = wave * 8 + (lane >> 3);
+  const int bkoff = ((lane & 7) ^ ((brow >> 1) & 7)) * EPC;
+  const bool b_ok = wave < 4 && brow < g.N;
+  const int ksteps = (g.K + BK - 1) / BK;
+  const int nsteps = g.taps * ksteps;
+  const bool ktail = (g.K % BK) != 0;
+
+  const char* pa[4];
+  const char* pb = zero;
+  int ia[4], ib = 0;
+  auto set_tap = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pa[i] = zero; ia[i] = 0;
+      if (a_pos[i] >= 0) {
+        int s2 = map_row(g.rm, a_pos[i], t);
+        if (s2 >= 0) { pa[i] = reinterpret_cast<const char*>(A + (long)(a_base[i] + s2) * g.lda + koff[i]); ia[i] = BK * (int)sizeof(T); }
+      }
+    }
+    pb = zero; ib = 0;
+    if (b_ok) { pb = reinterpret_cast<const char*>(W + (long)t * g.tapstride + (long)brow * g.ldw + bkoff); ib = BK * (int)sizeof(T); }
+  };
+  int itap = 0, ikb = 0;
+  set_tap(0);
+  auto issue = [&](int buf) {
+    char* sa = smem + buf * kSkStage + wave * 4096;
+    char* sb = smem + buf * kSkStage + kBig * 128 + wave * 1024;
+    const bool last = ktail && ikb == ksteps - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char* qa = pa[i];
+      if (last && ikb * BK + koff[i] >= g.K) qa = zero;
+      __builtin_amdgcn_global_load_lds((gas_ptr)qa, (las_ptr)(sa + i * 1024), 16, 0, 0);
+      pa[i] += ia[i];
+    }
+    if (wave < 4) {
+      const char* qb = pb;
+      if (last && ikb * BK + bkoff >= g.K) qb = zero;
+      __builtin_amdgcn_global_load_lds((gas_ptr)qb, (las_ptr)sb, 16, 0, 0);
+      pb += ib;
+    }
+    if (++ikb == ksteps) {
+      ikb = 0;
+      if (++itap < g.taps) set_tap(itap);
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  issue(0);
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
+    if (step + 1 < nsteps) issue(buf ^ 1);
+    const char* sa = smem + buf * kSkStage;
+    const char* sb = sa + kBig * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const u32x4 fa = *reinterpret_cast<const u32x4*>(sa + swz_off(wave * 32 + lr, 2 * ks + lh));
+      const u32x4 fb = *reinterpret_cast<const u32x4*>(sb + swz_off(lr, 2 * ks + lh));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // epilogue: 32x32 fp32 through a 4 KiB per-wave LDS slice -> 8 columns per lane (4 lanes per row, 16 rows per pass)
+  float* cs = reinterpret_cast<float*>(smem + wave * 4096);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr] = acc[r];
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  T* C = reinterpret_cast<T*>(g.C);
+  const int col8 = (lane & 3) * 8;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int row = it * 16 + (lane >> 2);
+    const int m = m0 + wave * 32 + row;
+    if (m < g.M && col8 < g.N) {
+      float v[8];
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(cs + row * 32 + col8);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(cs + row * 32 + col8 + 4);
+      v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3]; v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
+      store8(C + (long)m * g.ldc + col8, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // wgrad: dW[t][n1][n2] += sum_m dY[m][n1] * X[rowmap(m,t)][n2]
 // ---------------------------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -1155,6 +1271,15 @@ extern "C" int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, l
     hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
+  }
+  static const bool noskinny = getenv("OSUF_GEMM_NOSKINNY") != nullptr;
+  if (!noskinny && dtype == OSUF_DT_BF16 && N <= 32 && N % 8 == 0 && ldc % 8 == 0 && M >= 4096 && !C2 && !R && !U && !bias && !rscale && !stats &&
+      act == 0) {
+    const int lds_sk = 2 * kSkStage;
+    static bool sk_attr = ((void)hipFuncSetAttribute((const void*)gemm_nt_skinny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_sk), true);
+    (void)sk_attr;
+    hipLaunchKernelGGL(gemm_nt_skinny_kernel, dim3((M + kBig - 1) / kBig), dim3(512), lds_sk, stream, g);
+    return osuf_launch_status();
   }
   static const bool regstage = getenv("OSUF_GEMM_REGSTAGE") != nullptr;      // A/B switches for profiling only
   // 256^2 tiles once they fill most of the 256 CUs; OSUF_GEMM_BIG_MIN_TILES overrides the threshold (tests force 1, "off" = never)

@@ -213,6 +213,19 @@ def test_big_tile_gemm_kernel(monkeypatch, kind, k, L):
     assert relmax(p1.permute(0, 2, 1), ref) < 1e-2
 
 
+@pytest.mark.parametrize("N,K,k,L", [(16, 256, 3, 2048), (32, 328, 1, 4100), (8, 64, 3, 1500), (32, 1024, 1, 2304)])
+def test_skinny_n_gemm_kernel(N, K, k, L):
+    """gemm_nt_skinny_kernel (N <= 32, M >= 4096: the rank-r LoRA products) vs torch conv1d on the same bf16-rounded operands:
+    taps with zero padding at sample boundaries, K tail, M tail, N < 32."""
+    Bq = 3
+    x = torch.randn(Bq, L, K, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(N, K, k, device=DEV) / (K * k) ** 0.5).to(torch.bfloat16)
+    wp = w.permute(2, 0, 1).contiguous()                                 # [k][N][K]
+    y = ops.gemm_nt(x, wp, None, taps=k, lin=L, lout=L, stride=1, pad=k // 2, mode=0, out_shape=(Bq, L, N))
+    ref = F.conv1d(x.float().permute(0, 2, 1), w.float(), None, padding=k // 2).permute(0, 2, 1)
+    assert y.shape == ref.shape and relmax(y.float(), ref) < 1e-2
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("film", [False, True])
 def test_block_fn(dtype, tol, film):
