@@ -1147,6 +1147,113 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(WgradArgs g) {
 // deterministic second stage of the split wgrad: dW (+)= sum_s ws[s][t][i], i = n1*N2 + n2.
 // LAYOUT 0: dW[t][i] (the kernel's own order)   LAYOUT 1: dW[i][t] = torch's (Cout, Cin, k) conv weight layout -- the permute
 // is free here: a thread owns one i and writes its `taps` values contiguously.
+// ---------------------------------------------------------------------------------------------------------
+// Skinny wgrad (N2 <= 32: the rank-r LoRA gradients dB = dy^T u and, with the operands' roles swapped, dA^T = x^T du): a 256 (n1) x
+// 32 (n2) output tile per workgroup, 8 waves x one 32x32 MFMA tile, split over m with fp32 atomics into the small result
+// (32 consecutive floats per wave-instruction: the full-rate atomic shape).  Same dY loader and transposed fragment reads as
+// gemm_tn_big_kernel; the X tile is compact ([64 rows][64 B], no swizzle).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_tn_skinny_kernel(WgradArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKM = 64, ROWB = 512, TILEB = BKM * ROWB, XTILEB = BKM * 64, STAGE = TILEB + XTILEB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n1 = (g.N1 + kBig - 1) / kBig;
+  const int tile = blockIdx.x % tiles_n1;
+  const int t = (blockIdx.x / tiles_n1) % g.taps;
+  const int split = blockIdx.x / (tiles_n1 * g.taps);
+  const int n1_0 = tile * kBig;
+  const int m_begin = split * g.rows_per_split;
+  const int m_end = min(g.M, m_begin + g.rows_per_split);
+  if (m_begin >= m_end) return;
+  const bf16_t* dY = reinterpret_cast<const bf16_t*>(g.dY);
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(g.X);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  // dY loader (as gemm_tn_big_kernel): instruction i of this wave fills tile rows (wave*4+i)*2 + (lane>>5), LDS chunk lane&31
+  int srow[4], scol[4];
+  const char* py[4];
+  bool y_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    srow[i] = (wave * 4 + i) * 2 + (lane >> 5);
+    scol[i] = ((lane & 31) ^ ((srow[i] & 3) << 2)) * 8;
+    y_ok[i] = n1_0 + scol[i] < g.N1;
+    py[i] = reinterpret_cast<const char*>(dY + (long)(m_begin + srow[i]) * g.ldy + n1_0 + scol[i]);
+  }
+  const long ystep = (long)BKM * g.ldy * (long)sizeof(bf16_t);
+  // X loader: waves 0-3, one instruction each: rows wave*16 + (lane>>2), 16-B chunk lane&3 (8 columns of n2)
+  const int xrow = wave * 16 + (lane >> 2), xcol = (lane & 3) * 8;
+  const bool x_ok = wave < 4 && xcol < g.N2;
+  int xb = 0, xp = 0;
+  if (wave < 4) { const int m = m_begin + xrow; xb = m / g.rm.Lout; xp = m - xb * g.rm.Lout; }
+  auto issue = [&](int mb, int buf) {
+    char* sy = smem + buf * STAGE + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char* qy = (mb + srow[i] < m_end && y_ok[i]) ? py[i] : zero;
+      __builtin_amdgcn_global_load_lds((gas_ptr)qy, (las_ptr)(sy + i * 1024), 16, 0, 0);
+      py[i] += ystep;
+    }
+    if (wave < 4) {
+      const char* qx = zero;
+      if (x_ok && mb + xrow < m_end) {
+        const int s2 = map_row(g.rm, xp, t);
+        if (s2 >= 0) qx = reinterpret_cast<const char*>(X + (long)(xb * g.rm.Lin + s2) * g.ldx + xcol);
+      }
+      __builtin_amdgcn_global_load_lds((gas_ptr)qx, (las_ptr)(smem + buf * STAGE + TILEB + wave * 1024), 16, 0, 0);
+      xp += BKM;
+      while (xp >= g.rm.Lout) { xp -= g.rm.Lout; ++xb; }
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int ip = lane & 15, cb = ((lane >> 4) & 1) * 16, tq = ip >> 2, tp = ip & 3;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
+  const uint32_t offA = (8 * lh + tq) * ROWB + ((((wave * 32 + cb + 4 * tp) * 2)) ^ (tq << 6));
+  const uint32_t offB = TILEB + (8 * lh + tq) * 64 + (cb + 4 * tp) * 2;
+
+  issue(m_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  for (int mb = m_begin; mb < m_end; mb += BKM, buf ^= 1) {
+    if (mb + BKM < m_end) issue(mb + BKM, buf ^ 1);
+    const uint32_t base = lds0 + buf * STAGE;
+    u32x2 a0[4], a1[4], b0[4], b1[4];
+    OSUF_TR_READ(a0[0], base + offA, 0 * 16 * 512);  OSUF_TR_READ(a1[0], base + offA, (0 * 16 + 4) * 512);
+    OSUF_TR_READ(b0[0], base + offB, 0 * 16 * 64);   OSUF_TR_READ(b1[0], base + offB, (0 * 16 + 4) * 64);
+    OSUF_TR_READ(a0[1], base + offA, 1 * 16 * 512);  OSUF_TR_READ(a1[1], base + offA, (1 * 16 + 4) * 512);
+    OSUF_TR_READ(b0[1], base + offB, 1 * 16 * 64);   OSUF_TR_READ(b1[1], base + offB, (1 * 16 + 4) * 64);
+    OSUF_TR_READ(a0[2], base + offA, 2 * 16 * 512);  OSUF_TR_READ(a1[2], base + offA, (2 * 16 + 4) * 512);
+    OSUF_TR_READ(b0[2], base + offB, 2 * 16 * 64);   OSUF_TR_READ(b1[2], base + offB, (2 * 16 + 4) * 64);
+    OSUF_TR_READ(a0[3], base + offA, 3 * 16 * 512);  OSUF_TR_READ(a1[3], base + offA, (3 * 16 + 4) * 512);
+    OSUF_TR_READ(b0[3], base + offB, 3 * 16 * 64);   OSUF_TR_READ(b1[3], base + offB, (3 * 16 + 4) * 64);
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a0[0]), "+v"(a1[0]), "+v"(b0[0]), "+v"(b1[0]), "+v"(a0[1]), "+v"(a1[1]), "+v"(b0[1]), "+v"(b1[1]),
+                   "+v"(a0[2]), "+v"(a1[2]), "+v"(b0[2]), "+v"(b1[2]), "+v"(a0[3]), "+v"(a1[3]), "+v"(b0[3]), "+v"(b1[3]));
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const u32x4 va = {a0[ks][0], a0[ks][1], a1[ks][0], a1[ks][1]};
+      const u32x4 vb = {b0[ks][0], b0[ks][1], b1[ks][0], b1[ks][1]};
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, vb), acc, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  float* dW = g.dW + (long)t * g.tapstride;
+  if (lr < g.N2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n1 = n1_0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (n1 < g.N1) atomic_add_f32(dW + (long)n1 * g.ldw + (long)lr * g.es, acc[r]);
+    }
+  }
+}
+
 // sum of `splits` partial float4s that lie `stride` floats apart; four independent chains so that four loads are in flight per
 // lane (a single dependent chain waits out one L2 / HBM round trip per split)
 __device__ __forceinline__ f32x4 sum_partials(const float* p, long stride, int splits) {
@@ -1356,6 +1463,28 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
   if (N1 % epc || N2 % epc || ldy % epc || ldx % epc) return OSUF_EINVAL;
   if (!aligned16(dY) || !aligned16(X)) return OSUF_EINVAL;
   const int bkm = dtype == OSUF_DT_BF16 ? 64 : 32;
+  static const bool noskinny = getenv("OSUF_GEMM_NOSKINNY") != nullptr;
+  if (!noskinny && splits <= 0 && dtype == OSUF_DT_BF16 && N2 <= 32 && M >= 4096) {
+    WgradArgs gs;
+    gs.dY = dY; gs.X = X; gs.dW = dW; gs.ws = nullptr; gs.es = es; gs.ldy = ldy; gs.ldx = ldx; gs.ldw = ldw; gs.tapstride = tapstride;
+    gs.M = M; gs.N1 = N1; gs.N2 = N2; gs.taps = taps; gs.rm = RowMap{Lin, Lout, stride, pad, mode};
+    const int tiles_n1 = (N1 + kBig - 1) / kBig;
+    int sp = (512 + tiles_n1 * taps - 1) / (tiles_n1 * taps);          // ~2 workgroups per CU
+    int rows = (M + sp - 1) / sp;
+    rows = ((rows + 63) / 64) * 64;
+    if (rows < 256) rows = 256;
+    sp = (M + rows - 1) / rows;
+    gs.rows_per_split = rows;
+    if (!accumulate) {
+      if (out_layout == 0 && !(ldw == N2 && (taps == 1 || tapstride == (long)N1 * N2))) return OSUF_EINVAL;
+      (void)hipMemsetAsync(dW, 0, (size_t)taps * N1 * N2 * sizeof(float), stream);
+    }
+    const int lds_sk = 2 * (64 * 512 + 64 * 64);
+    static bool sk_attr = ((void)hipFuncSetAttribute((const void*)gemm_tn_skinny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_sk), true);
+    (void)sk_attr;
+    hipLaunchKernelGGL(gemm_tn_skinny_kernel, dim3(tiles_n1 * taps * sp), dim3(512), lds_sk, stream, gs);
+    return osuf_launch_status();
+  }
   {
     int rows, sp;
     if (splits <= 0 && tn_big_plan(dtype, M, N1, N2, taps, &rows, &sp)) {

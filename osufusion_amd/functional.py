@@ -227,8 +227,14 @@ def adapter_grads(ad: Adapter, dy, x, y, bias, kind: str, cache: PackCache, sums
         u = ops.gemm_nt(x, pa, None, taps=k, lin=Lin, lout=Lout, stride=stride, pad=pad, mode=mode, out_shape=(B_, Lout, r))
         du = ops.gemm_nt(dy, pbt, None, out_shape=(B_, Lout, r))
         db = ops.gemm_tn(dy, u, n1=O)[0] * sg[:, None]                                             # (O, r)
-        da = ops.gemm_tn(du, x, taps=k, lin=Lin, lout=Lout, stride=stride, pad=pad, mode=mode, n1=r, conv_layout=conv)
-        da = da if conv else da[0]
+        if kind == "same":
+            # dA^T instead of dA, so that the rank-r operand is the SECOND one (the skinny wgrad kernel wants N2 = r):
+            #   G[t'][i][q] = sum_m' x[m'][i] du[m' + t' - (k-1-pad)][q]  ==  dA[q][i][k-1-t']      (same set of (row, tap) pairs)
+            gt = ops.gemm_tn(x, du, taps=k, lin=Lin, lout=Lout, stride=1, pad=k - 1 - pad, mode=0, n1=I)
+            da = gt.flip(0).permute(2, 1, 0).contiguous() if conv else gt[0].t().contiguous()
+        else:
+            da = ops.gemm_tn(du, x, taps=k, lin=Lin, lout=Lout, stride=stride, pad=pad, mode=mode, n1=r, conv_layout=conv)
+            da = da if conv else da[0]
         dm = None
         if ad.m is not None:
             if sums is not None:                           # (sum dy*y, sum dy) already produced by the GroupNorm backward

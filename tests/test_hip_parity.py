@@ -226,6 +226,23 @@ def test_skinny_n_gemm_kernel(N, K, k, L):
     assert y.shape == ref.shape and relmax(y.float(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("N1,N2,k,L", [(256, 16, 1, 2048), (328, 32, 3, 1500), (1024, 8, 3, 1400), (40, 24, 1, 4100)])
+def test_skinny_wgrad_kernel(N1, N2, k, L):
+    """gemm_tn_skinny_kernel (N2 <= 32, M >= 4096: dB = dy^T u and dA^T = x^T du of the LoRA path) vs an fp64 reference on the same
+    bf16-rounded operands: taps with zero padding at sample edges, N1 / N2 / M tails, split-over-m atomics."""
+    Bq = 3
+    dy = torch.randn(Bq, L, N1, device=DEV).to(torch.bfloat16)
+    x = torch.randn(Bq, L, N2, device=DEV).to(torch.bfloat16)
+    got = ops.gemm_tn(dy, x, taps=k, lin=L, lout=L, stride=1, pad=k // 2, mode=0, n1=N1)          # [k][N1][N2]
+    ref = torch.zeros(k, N1, N2, dtype=torch.float64, device=DEV)
+    xd, yd = x.double(), dy.double()
+    for t in range(k):
+        sh = t - k // 2                                                     # source row = m + sh inside the sample
+        lo, hi = max(0, -sh), min(L, L - sh)
+        ref[t] = torch.einsum("bmn,bmk->nk", yd[:, lo:hi], xd[:, lo + sh:hi + sh])
+    assert got.shape == ref.shape and relmax(got, ref) < 1e-4
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("film", [False, True])
 def test_block_fn(dtype, tol, film):
