@@ -1431,7 +1431,8 @@ extern "C" int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, l
 static bool tn_big_plan(int dtype, int M, int N1, int N2, int taps, int* rows_out, int* splits_out) {
   const char* bigenv = getenv("OSUF_GEMM_BIG_MIN_TILES");
   const bool forced = bigenv && atol(bigenv) == 1, off = bigenv && atol(bigenv) <= 0;
-  if (dtype != OSUF_DT_BF16 || off || !(forced || (N1 >= 192 && N2 >= 192))) return false;
+  static const int lo = getenv("OSUF_TN_BIG_MIN_N") ? atoi(getenv("OSUF_TN_BIG_MIN_N")) : 64;
+  if (dtype != OSUF_DT_BF16 || off || !(forced || (N1 >= lo && N2 >= lo && (N1 >= 192 || N2 >= 192)))) return false;
   const int btiles = ((N1 + kBig - 1) / kBig) * ((N2 + kBig - 1) / kBig);
   int sp = (256 + btiles * taps / 2) / (btiles * taps);        // one workgroup per CU: about one round of the 256 CUs
   if (sp < 1) sp = 1;
