@@ -158,6 +158,18 @@ int osuf_skinny_bwd(int mode, const float* dy, long lddy, const float* y, long l
                     float* dx, long lddx, float* dW, float* db, int M, int N, int K, int in_act, int out_act, int accumulate,
                     hipStream_t stream);
 
+/* ---- audio front end (audio.hip)    replaces: scripts/dataset_creator.py:36-55 load_audio's feature step,
+ *      np.log(np.abs(librosa.vqt(y, sr=22050, hop_length=176, fmin=C0, n_bins=96, bins_per_octave=12)) + 1e-10)
+ *      (called from trainer.py:104, trainer_peft.py:107, inference_gradio.py:56).
+ *      wave_pad: zero-padded mono waveform (n_pad floats, >= (frames-1)*hop + K); bank: [2*bins][K] fp32 wavelet bank (real rows,
+ *      then imaginary rows; built by osufusion_amd/audio.py); scale: [bins] = sqrt(filter length); spec_ws: frames*2*bins floats;
+ *      out[k][t] = log(scale[k] * |sum_n wave_pad[t*hop + n] * (bank[k][n] + i bank[bins+k][n])| + eps), row stride ldo.
+ *      hop and K multiples of 4.  osuf_vqt_logmag is the second stage alone (spec: [frames][ld >= 2*bins]). ---- */
+int osuf_log_vqt(const float* wave_pad, long n_pad, const float* bank, int K, int bins, int hop, const float* scale, float eps,
+                 float* spec_ws, float* out, long ldo, long frames, hipStream_t stream);
+int osuf_vqt_logmag(const float* spec, long ld, float* out, long ldo, const float* scale, int bins, long frames, float eps,
+                    hipStream_t stream);
+
 /* Measurement aid (no reference counterpart): sustained shader clock under an MFMA (mode 1) or VALU (mode 0) load.
  * out[2*block] = shader cycles, out[2*block+1] = 100 MHz wall ticks. */
 int osuf_clock_probe(int blocks, int iters, int mode, long* out, hipStream_t stream);

@@ -53,6 +53,8 @@ SIGNATURES = {
     "osuf_pack_weight": [P, I, I, I, I, P, L, L, P, L, L, I, P],
     "osuf_dora_effective": [P, P, P, P, I, I, I, F, P, P, P],
     "osuf_clock_probe": [I, I, I, P, P],
+    "osuf_log_vqt": [P, L, P, I, I, I, P, F, P, P, L, L, P],
+    "osuf_vqt_logmag": [P, L, P, L, P, I, L, F, P],
     "osuf_skinny_fwd": [I, P, L, P, P, P, L, I, I, I, I, I, P],
     "osuf_skinny_bwd": [I, P, L, P, L, P, L, P, P, L, P, P, I, I, I, I, I, I, P],
 }

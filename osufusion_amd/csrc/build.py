@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
-SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "elementwise.hip", "skinny.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "elementwise.hip", "skinny.hip", "audio.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 LIB = HERE / "libosuf_hip.so"
 

@@ -450,3 +450,16 @@ def dora_effective(w: torch.Tensor, a: torch.Tensor, b: torch.Tensor, mag: Optio
 def cast_f32_bf16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     call("osuf_cast_f32_bf16", _p(src), _p(dst), src.numel(), _stream())
     return dst
+
+
+def log_vqt(wave_pad: torch.Tensor, bank: torch.Tensor, scale: torch.Tensor, hop: int, frames: int, eps: float = 1e-10) -> torch.Tensor:
+    """out[k][t] = log(scale[k] |sum_n wave_pad[t*hop+n] (bank[k][n] + i bank[bins+k][n])| + eps) -> (bins, frames) fp32 (audio.hip)."""
+    assert wave_pad.is_cuda and wave_pad.dtype == torch.float32 and wave_pad.dim() == 1 and wave_pad.is_contiguous()
+    assert bank.dtype == torch.float32 and bank.dim() == 2 and bank.is_contiguous() and bank.shape[0] % 2 == 0
+    bins, K = bank.shape[0] // 2, bank.shape[1]
+    assert scale.dtype == torch.float32 and scale.numel() == bins and hop % 4 == 0 and K % 4 == 0
+    assert (frames - 1) * hop + K <= wave_pad.numel()
+    ws = torch.empty((frames, 2 * bins), dtype=torch.float32, device=wave_pad.device)
+    out = torch.empty((bins, frames), dtype=torch.float32, device=wave_pad.device)
+    call("osuf_log_vqt", _p(wave_pad), wave_pad.numel(), _p(bank), K, bins, hop, _p(scale), eps, _p(ws), _p(out), frames, frames, _stream())
+    return out
