@@ -35,6 +35,7 @@ STEP_TFLOP = 125.1                      # 3 x 1,303 GFLOP/sample x 32 (SURVEY.md
 # on itself, so the offline measurement is quoted (algorithmic bytes of the dK/dV kernel over the same mix: 289 MB).  Re-measured
 # after the kernels were software-pipelined, stand-alone at N=4096 (profiles/r01_pmc2/): dK/dV 2 x 287.0 MiB fetched + 64.0 MiB
 # written = 655 MB, i.e. x 0.4423 (the mix's mean N-weight) = 289.7 MB per launch -- unchanged.
+# End of round 1 (scale / RoPE folded into the backward epilogues, profiles/r01_pmc3/): 2 x 280.2 MiB + 64.0 MiB = 655 MB at N=4096 -- unchanged.
 PMC_TRAFFIC_BYTES = {"osuf_mqa_bwd_dkv": 2 * 129.9e6 + 29.7e6, "osuf_mqa_bwd_dq": 2 * 182.0e6 + 237.5e6, "osuf_mqa_fwd": 2 * 133.4e6 + 219.0e6}
 
 
