@@ -144,6 +144,19 @@ int osuf_pack_weight(const float* w, int O, int I, int k, int out_dtype, void* F
  *   V = W + scaling * B A;   g = mag / ||V||_row  (1 without mag);   Weff = g * V.   g (O floats) may be NULL. */
 int osuf_dora_effective(const float* W, const float* A, const float* B, const float* mag, int O, int IK, int r, float scaling,
                         float* Weff, float* g, hipStream_t stream);
+/* The same effective weight without the full-size fp32 round trip (what the training step uses):
+ *   osuf_dora_gain            g[o] = mag[o] / ||W[o] + s (BA)[o]||_2 (mag NULL: g = 1; partial = workspace of ceil(I/32)*O floats), plus
+ *                             the transposed rank-r operand (s g B)^T = [r][O] in f32 (sgbt32) and bf16 (sgbt16), either may be NULL
+ *   osuf_pack_weight_adapted  osuf_pack_weight of g[o] * (w + s * B A), formed tile by tile from the frozen master (g NULL: g = 1) */
+int osuf_dora_gain(const float* W, const float* A, const float* B, const float* mag, int O, int I, int k, int r, float scaling,
+                   float* partial, float* g, float* sgbt32, void* sgbt16, hipStream_t stream);
+int osuf_pack_weight_adapted(const float* w, const float* A, const float* B, const float* g, float scaling, int r, int O, int I, int k,
+                             int out_dtype, void* F, long f_ld, long f_tapstride, void* D, long d_ld, long d_tapstride, int dkind,
+                             hipStream_t stream);
+/* Tail of the rank-r adapter gradients in one launch: dB (+)= sg[o] * tb[o][q]; dA[q][i][t] (+)= gt[k-1-t][i][q]; and, when dm is
+ * given, dm (+)= (s0 - bias * s1) / m   (tb = dy^T u, gt = x^T du per tap, s0 = sum dy*y, s1 = sum dy; bias may be NULL). */
+int osuf_adapter_finish(const float* tb, const float* sg, float* dB, const float* gt, float* dA, const float* s0, const float* s1,
+                        const float* bias, const float* m, float* dm, int O, int I, int k, int r, int accumulate, hipStream_t stream);
 
 /* ---- embedding-sized linears (skinny.hip)    replaces: time_mlp / cond_mlp (modules/unet.py:356-367), the FiLM projection
  *      (residual.py:104-111,126-133) and GlobalContext's squeeze-excite MLP (residual.py:20-26,33-37) -- nn.Linear / 1x1 Conv1d on

@@ -52,6 +52,9 @@ SIGNATURES = {
     "osuf_cast_f32_bf16": [P, P, L, P],
     "osuf_pack_weight": [P, I, I, I, I, P, L, L, P, L, L, I, P],
     "osuf_dora_effective": [P, P, P, P, I, I, I, F, P, P, P],
+    "osuf_dora_gain": [P, P, P, P, I, I, I, I, F, P, P, P, P, P],
+    "osuf_adapter_finish": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "osuf_pack_weight_adapted": [P, P, P, P, F, I, I, I, I, I, P, L, L, P, L, L, I, P],
     "osuf_clock_probe": [I, I, I, P, P],
     "osuf_log_vqt": [P, L, P, I, I, I, P, F, P, P, L, L, P],
     "osuf_vqt_logmag": [P, L, P, L, P, I, L, F, P],

@@ -293,12 +293,41 @@ extern "C" int osuf_cast_f32_bf16(const float* src, void* dst, long n, hipStream
 // (the torch path did permute + cast + contiguous (+ flip / cat) per layout: ~1.4 k small launches and ~9 ms of a 295 ms step)
 // One 32x32 (o, i) tile per block, up to 4 taps at a time through LDS so both outputs are written with contiguous rows.
 // ------------------------------------------------------------------------------------------------------
-template <typename TO>
+// ADAPT: the packed value is the LoRA / DoRA effective weight g[o] * (w + s * sum_q B[o][q] A[q][i][t]) (q ascending, fp32 FMA chain),
+// formed on the fly from the frozen master and the rank-r factors -- the full-size fp32 effective weight is never materialised.
+struct AdaptArgs { const float* A; const float* B; const float* g; float s; int r; };
+
+// lora_A / lora_B slabs of one 32 x 32 (o, i) tile -> LDS: As[q][i_local * k + t], Bs[o_local][q], gs[o_local]
+__device__ __forceinline__ void stage_adapter(const AdaptArgs& ad, float* As, float* Bs, float* gs, int O, int I, int k, int o0, int i0) {
+  const int wk = 32 * k;
+  for (int e = threadIdx.x; e < ad.r * wk; e += 256) {
+    const int q = e / wk, c = e - q * wk;
+    As[e] = (i0 * k + c < I * k) ? ad.A[(long)q * I * k + (long)i0 * k + c] : 0.f;
+  }
+  for (int e = threadIdx.x; e < 32 * ad.r; e += 256) Bs[e] = (o0 + e / ad.r < O) ? ad.B[(long)o0 * ad.r + e] : 0.f;
+  if (threadIdx.x < 32) gs[threadIdx.x] = (ad.g && o0 + threadIdx.x < O) ? ad.g[o0 + threadIdx.x] : 1.f;
+  __syncthreads();
+}
+
+__device__ __forceinline__ float adapted_value(const AdaptArgs& ad, const float* As, const float* Bs, int k, int row, int col, int t, float w) {
+  float acc = 0.f;
+  const float* a = As + col * k + t;
+  const float* b = Bs + row * ad.r;
+  for (int q = 0; q < ad.r; ++q) acc = fmaf(b[q], a[q * 32 * k], acc);
+  return fmaf(ad.s, acc, w);
+}
+
+template <typename TO, bool ADAPT>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int O, int I, int k, TO* F, long f_ld, long f_ts, TO* D,
-                                                          long d_ld, long d_ts, int dkind) {
+                                                          long d_ld, long d_ts, int dkind, AdaptArgs ad) {
   __shared__ float tile[4][32][33];
+  extern __shared__ float adapt_lds[];                      // ADAPT: As | Bs | gs
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   const int o0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
+  float* As = adapt_lds;
+  float* Bs = As + (ADAPT ? ad.r * 32 * k : 0);
+  float* gs = Bs + (ADAPT ? 32 * ad.r : 0);
+  if constexpr (ADAPT) stage_adapter(ad, As, Bs, gs, O, I, k, o0, i0);
   for (int t0 = 0; t0 < k; t0 += 4) {
     const int nt = min(4, k - t0);
     for (int r = ty; r < 32; r += 8) {
@@ -306,7 +335,8 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
       if (o < O && i < I) {
         const float* src = w + ((long)o * I + i) * k + t0;
         for (int t = 0; t < nt; ++t) {
-          const float v = src[t];
+          float v = src[t];
+          if constexpr (ADAPT) v = gs[r] * adapted_value(ad, As, Bs, k, r, tx, t0 + t, v);
           tile[t][r][tx] = v;
           if (F) ElemTraits<TO>::store(F + (long)(t0 + t) * f_ts + (long)o * f_ld + i, v);
         }
@@ -340,11 +370,91 @@ extern "C" int osuf_pack_weight(const float* w, int O, int I, int k, int out_dty
                                 long d_tapstride, int dkind, hipStream_t stream) {
   if (!w || O <= 0 || I <= 0 || k <= 0 || dkind < 0 || dkind > 2 || (dkind != 0 && k != 3) || (!F && !D)) return OSUF_EINVAL;
   dim3 grid((I + 31) / 32, (O + 31) / 32);
+  const AdaptArgs none{nullptr, nullptr, nullptr, 0.f, 0};
   if (out_dtype == OSUF_DT_BF16)
-    hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, grid, dim3(256), 0, stream, w, O, I, k, (bf16_t*)F, f_ld, f_tapstride, (bf16_t*)D, d_ld, d_tapstride, dkind);
+    hipLaunchKernelGGL((pack_weight_kernel<bf16_t, false>), grid, dim3(256), 0, stream, w, O, I, k, (bf16_t*)F, f_ld, f_tapstride, (bf16_t*)D, d_ld, d_tapstride, dkind, none);
   else if (out_dtype == OSUF_DT_F32)
-    hipLaunchKernelGGL(pack_weight_kernel<float>, grid, dim3(256), 0, stream, w, O, I, k, (float*)F, f_ld, f_tapstride, (float*)D, d_ld, d_tapstride, dkind);
+    hipLaunchKernelGGL((pack_weight_kernel<float, false>), grid, dim3(256), 0, stream, w, O, I, k, (float*)F, f_ld, f_tapstride, (float*)D, d_ld, d_tapstride, dkind, none);
   else return OSUF_EUNSUPPORTED;
+  return osuf_launch_status();
+}
+
+// The same two layouts of the LoRA / DoRA effective weight (see AdaptArgs): A (r, I, k), B (O, r), g (O) or NULL (= 1).
+extern "C" int osuf_pack_weight_adapted(const float* w, const float* A, const float* B, const float* g, float scaling, int r, int O, int I, int k,
+                                        int out_dtype, void* F, long f_ld, long f_tapstride, void* D, long d_ld, long d_tapstride, int dkind,
+                                        hipStream_t stream) {
+  if (!w || !A || !B || r <= 0 || O <= 0 || I <= 0 || k <= 0 || dkind < 0 || dkind > 2 || (dkind != 0 && k != 3) || (!F && !D)) return OSUF_EINVAL;
+  const size_t lds = ((size_t)r * 32 * k + 32 * r + 32) * sizeof(float);
+  if (lds > 96 * 1024) return OSUF_EUNSUPPORTED;
+  dim3 grid((I + 31) / 32, (O + 31) / 32);
+  const AdaptArgs ad{A, B, g, scaling, r};
+  if (out_dtype == OSUF_DT_BF16) {
+    if (lds > 32 * 1024) (void)hipFuncSetAttribute((const void*)pack_weight_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((pack_weight_kernel<bf16_t, true>), grid, dim3(256), lds, stream, w, O, I, k, (bf16_t*)F, f_ld, f_tapstride, (bf16_t*)D, d_ld, d_tapstride, dkind, ad);
+  } else if (out_dtype == OSUF_DT_F32) {
+    if (lds > 32 * 1024) (void)hipFuncSetAttribute((const void*)pack_weight_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((pack_weight_kernel<float, true>), grid, dim3(256), lds, stream, w, O, I, k, (float*)F, f_ld, f_tapstride, (float*)D, d_ld, d_tapstride, dkind, ad);
+  } else return OSUF_EUNSUPPORTED;
+  return osuf_launch_status();
+}
+
+// DoRA gain g[o] = mag[o] / ||W[o] + s (BA)[o]||_2 without forming the row anywhere: per-tile partial sums of squares
+// (partial[i_tile][o], fixed order -> deterministic), then one thread per output channel finishes g and writes the
+// transposed rank-r operand (s g B)^T = [r][O] that the adapter-gradient GEMM du = dy (s g B) consumes, in f32 and bf16.
+__global__ __launch_bounds__(256) void dora_sumsq_kernel(const float* __restrict__ w, int O, int I, int k, AdaptArgs ad, float* __restrict__ partial) {
+  extern __shared__ float adapt_lds[];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int o0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
+  float* As = adapt_lds;
+  float* Bs = As + ad.r * 32 * k;
+  float* gs = Bs + 32 * ad.r;
+  stage_adapter(ad, As, Bs, gs, O, I, k, o0, i0);
+  for (int r = ty; r < 32; r += 8) {
+    const int o = o0 + r, i = i0 + tx;
+    float ss = 0.f;
+    if (o < O && i < I) {
+      const float* src = w + ((long)o * I + i) * k;
+      for (int t = 0; t < k; ++t) {
+        const float v = adapted_value(ad, As, Bs, k, r, tx, t, src[t]);
+        ss = fmaf(v, v, ss);
+      }
+    }
+    ss = group_sum<32>(ss);
+    if (tx == 0 && o < O) partial[(long)blockIdx.x * O + o] = ss;
+  }
+}
+
+__global__ __launch_bounds__(256) void dora_gain_kernel(const float* __restrict__ partial, int ntiles, const float* __restrict__ mag,
+                                                        const float* __restrict__ Bm, int O, int r, float s, float* __restrict__ g_out,
+                                                        float* __restrict__ sgbt32, bf16_t* __restrict__ sgbt16) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= O) return;
+  float g = 1.f;
+  if (mag) {
+    float ss = 0.f;
+    for (int t = 0; t < ntiles; ++t) ss += partial[(long)t * O + o];
+    g = mag[o] / sqrtf(ss);
+  }
+  g_out[o] = g;
+  for (int q = 0; q < r; ++q) {
+    const float v = s * g * Bm[(long)o * r + q];
+    if (sgbt32) sgbt32[(long)q * O + o] = v;
+    if (sgbt16) sgbt16[(long)q * O + o] = f32_to_bf16(v);
+  }
+}
+
+extern "C" int osuf_dora_gain(const float* W, const float* A, const float* B, const float* mag, int O, int I, int k, int r, float scaling,
+                              float* partial, float* g, float* sgbt32, void* sgbt16, hipStream_t stream) {
+  if (!W || !A || !B || !g || O <= 0 || I <= 0 || k <= 0 || r <= 0 || (mag && !partial)) return OSUF_EINVAL;
+  const int ntiles = (I + 31) / 32;
+  if (mag) {
+    const size_t lds = ((size_t)r * 32 * k + 32 * r + 32) * sizeof(float);
+    if (lds > 96 * 1024) return OSUF_EUNSUPPORTED;
+    if (lds > 32 * 1024) (void)hipFuncSetAttribute((const void*)dora_sumsq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const AdaptArgs ad{A, B, nullptr, scaling, r};
+    hipLaunchKernelGGL(dora_sumsq_kernel, dim3(ntiles, (O + 31) / 32), dim3(256), lds, stream, W, O, I, k, ad, partial);
+  }
+  hipLaunchKernelGGL(dora_gain_kernel, dim3((O + 255) / 256), dim3(256), 0, stream, partial, ntiles, mag, B, O, r, scaling, g, sgbt32, (bf16_t*)sgbt16);
   return osuf_launch_status();
 }
 
@@ -436,6 +546,44 @@ extern "C" int osuf_dora_effective(const float* W, const float* A, const float* 
   else if (oc == 2) OSUF_DORA_LAUNCH(2);
   else OSUF_DORA_LAUNCH(1);
 #undef OSUF_DORA_LAUNCH
+  return osuf_launch_status();
+}
+
+// Tail of the adapter gradients (functional.adapter_grads), one launch instead of ~10 small torch kernels per adapted layer:
+//   dB[o][q]    (+)= sg[o] * tb[o][q]                      tb = dy^T u, sg = s * g
+//   dA[q][i][t] (+)= gt[k-1-t][i][q]                       gt = the swapped, tap-flipped wgrad x^T du (rank-r operand second)
+//   dm[o]       (+)= (s0[o] - bias[o] * s1[o]) / m[o]      s0 = sum_m dy*y, s1 = sum_m dy   (dm / bias may be NULL)
+__global__ __launch_bounds__(256) void adapter_finish_kernel(const float* __restrict__ tb, const float* __restrict__ sg, float* dB,
+                                                             const float* __restrict__ gt, float* dA, const float* __restrict__ s0,
+                                                             const float* __restrict__ s1, const float* __restrict__ bias,
+                                                             const float* __restrict__ m, float* dm, int O, int I, int k, int r, int acc) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx < (long)O * r) {
+    const float v = sg[idx / r] * tb[idx];
+    dB[idx] = acc ? dB[idx] + v : v;
+  }
+  if (idx < (long)r * I * k) {
+    const int q = (int)(idx / ((long)I * k));
+    const int rem = (int)(idx - (long)q * I * k);
+    const int i = rem / k, t = rem - i * k;
+    const float v = gt[((long)(k - 1 - t) * I + i) * r + q];
+    dA[idx] = acc ? dA[idx] + v : v;
+  }
+  if (dm && idx < O) {
+    const float v = (s0[idx] - (bias ? bias[idx] * s1[idx] : 0.f)) / m[idx];
+    dm[idx] = acc ? dm[idx] + v : v;
+  }
+}
+
+extern "C" int osuf_adapter_finish(const float* tb, const float* sg, float* dB, const float* gt, float* dA, const float* s0, const float* s1,
+                                   const float* bias, const float* m, float* dm, int O, int I, int k, int r, int accumulate,
+                                   hipStream_t stream) {
+  if (!tb || !sg || !dB || !gt || !dA || O <= 0 || I <= 0 || k <= 0 || r <= 0 || (dm && (!s0 || !m || (bias && !s1)))) return OSUF_EINVAL;
+  long n = (long)O * r;
+  if ((long)r * I * k > n) n = (long)r * I * k;
+  if (O > n) n = O;
+  hipLaunchKernelGGL(adapter_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tb, sg, dB, gt, dA, s0, s1, bias, m, dm, O, I,
+                     k, r, accumulate);
   return osuf_launch_status();
 }
 

@@ -44,21 +44,41 @@ class PackCache:
             return hit[1]
         ws = weights if isinstance(weights, (tuple, list)) else (weights,)
         with torch.no_grad():
-            ws = [w.detach().float().contiguous() for w in ws]
             if len(ws) == 1:
-                pair = ops.pack_weight(ws[0], dt, kind)
+                pair = _pack_one(ws[0], dt, kind)
             else:
                 I = ws[0].shape[1]
                 total = sum(w.shape[0] for w in ws)
-                fwd = torch.empty((1, total, I), dtype=dt, device=ws[0].device)
-                dgr = torch.empty((1, I, total), dtype=dt, device=ws[0].device)
+                dev = ws[0].device
+                fwd = torch.empty((1, total, I), dtype=dt, device=dev)
+                dgr = torch.empty((1, I, total), dtype=dt, device=dev)
                 off = 0
                 for w in ws:
-                    ops.pack_weight(w, dt, kind, fwd=fwd, dgrad=dgr, row_offset=off)
+                    _pack_one(w, dt, kind, fwd=fwd, dgrad=dgr, row_offset=off)
                     off += w.shape[0]
                 pair = (fwd, dgr)
         self._d[key] = (ver, pair)
         return pair
+
+
+def _pack_one(w, dt, kind, **kw):
+    """osuf_pack_weight of a master weight, or of an adapter's effective weight straight from its factors."""
+    if isinstance(w, EffWeight):
+        ad = w.ad
+        return ops.pack_weight(ad.w.detach().float().contiguous(), dt, kind, adapt=(ad.a.detach().float().contiguous(),
+                               ad.b.detach().float().contiguous(), w.g if ad.m is not None else None, ad.scaling), **kw)
+    return ops.pack_weight(w.detach().float().contiguous(), dt, kind, **kw)
+
+
+class EffWeight:
+    """Stand-in for an Adapter's effective weight g*(W + s*BA): it has the base weight's shape and is only ever materialised
+    inside the pack kernel (osuf_pack_weight_adapted), in the GEMM operand layouts."""
+
+    def __init__(self, ad, g) -> None:
+        self.ad, self.g, self.shape, self.device = ad, g, ad.w.shape, ad.w.device
+
+    def dim(self) -> int:
+        return len(self.shape)
 
 
 # ---- direct gradient accumulation ---------------------------------------------------------------------------
@@ -194,14 +214,16 @@ class Adapter:
         return (self.w, self.a, self.b) + ((self.m,) if self.m is not None else ())
 
     def effective(self):
-        """-> (Weff like w, g (O,)); cached until a source parameter changes."""
+        """-> (EffWeight standing for g*(W + s*BA), g (O,)); the gain is cached until a source parameter changes."""
         ver = (_WEIGHT_EPOCH, *[(p._version, p.data_ptr()) for p in self.params])
         if self._eff is None or self._eff[0] != ver:
             with torch.no_grad():
                 m = self.m.detach().float().reshape(-1).contiguous() if self.m is not None else None
-                weff, g = ops.dora_effective(self.w.detach().float().contiguous(), self.a.detach().float().contiguous(),
-                                             self.b.detach().float().contiguous(), m, self.scaling)
-            self._eff = (ver, weff, g)
+                g, t32, t16 = ops.dora_gain(self.w.detach().float().contiguous(), self.a.detach().float().contiguous(),
+                                            self.b.detach().float().contiguous(), m, self.scaling)
+                self.sg = g * self.scaling
+                self.sgbt = {torch.float32: t32, torch.bfloat16: t16}          # (s g B)^T, the operand of du = dy (s g B)
+            self._eff = (ver, EffWeight(self, g), g)
         return self._eff[1], self._eff[2]
 
 
@@ -222,28 +244,45 @@ def adapter_grads(ad: Adapter, dy, x, y, bias, kind: str, cache: PackCache, sums
     Lout, stride, pad, mode = _conv_geom(kind, k, Lin)
     with torch.no_grad():
         pa = cache.packs(("lora_a", id(ad), kind, dt), (ad.a,), ad.a, "same", dt)[0]                       # [k][r][I]
-        sg = g * ad.scaling
-        pbt = cache.packs(("lora_bt", id(ad), dt), ad.params, (ad.b.detach().float().reshape(O, r) * sg[:, None]), "same", dt)[1]   # [1][r][O]
+        sg, pbt = ad.sg, ad.sgbt[dt]                                                               # [1][r][O]
         u = ops.gemm_nt(x, pa, None, taps=k, lin=Lin, lout=Lout, stride=stride, pad=pad, mode=mode, out_shape=(B_, Lout, r))
         du = ops.gemm_nt(dy, pbt, None, out_shape=(B_, Lout, r))
-        db = ops.gemm_tn(dy, u, n1=O)[0] * sg[:, None]                                             # (O, r)
+        tb = ops.gemm_tn(dy, u, n1=O)                                                              # [1][O][r] = dy^T u
+        s0 = s1 = None
+        if ad.m is not None:
+            if sums is not None:                           # (sum dy*y, sum dy) already produced by the GroupNorm backward
+                s0, s1 = sums
+            else:
+                s0 = ops.wcolsum(dy, y, None, B_, Lout).sum(0)
+                s1 = ops.colsum(dy, O) if bias is not None else None
+        bias32 = bias.detach().float().contiguous() if bias is not None else None
         if kind == "same":
             # dA^T instead of dA, so that the rank-r operand is the SECOND one (the skinny wgrad kernel wants N2 = r):
             #   G[t'][i][q] = sum_m' x[m'][i] du[m' + t' - (k-1-pad)][q]  ==  dA[q][i][k-1-t']      (same set of (row, tap) pairs)
             gt = ops.gemm_tn(x, du, taps=k, lin=Lin, lout=Lout, stride=1, pad=k - 1 - pad, mode=0, n1=I)
-            da = gt.flip(0).permute(2, 1, 0).contiguous() if conv else gt[0].t().contiguous()
-        else:
-            da = ops.gemm_tn(du, x, taps=k, lin=Lin, lout=Lout, stride=stride, pad=pad, mode=mode, n1=r, conv_layout=conv)
-            da = da if conv else da[0]
+            # one kernel scales dB, un-flips / transposes dA and finishes dm -- straight into the parameters' .grad when the
+            # Trainer's flat gradient buffer is in use
+            tgt = [grad_target(ad.a), grad_target(ad.b)] + ([grad_target(ad.m)] if ad.m is not None else [])
+            direct = all(t is not None for t in tgt)
+            da = tgt[0] if direct else torch.empty(ad.a.shape, dtype=torch.float32, device=x.device)
+            db = tgt[1] if direct else torch.empty(ad.b.shape, dtype=torch.float32, device=x.device)
+            dm = None
+            if ad.m is not None:
+                dm = tgt[2] if direct else torch.empty(ad.m.shape, dtype=torch.float32, device=x.device)
+            ops.adapter_finish(tb, sg, db, gt, da, s0, s1, bias32, ad.m.detach().float().contiguous() if ad.m is not None else None, dm,
+                               O, I, k, r, accumulate=direct)
+            if direct:
+                for p_ in (ad.a, ad.b) + ((ad.m,) if ad.m is not None else ()):
+                    grad_done(p_)
+                return None, None, None
+            return da, db, dm
+        db = tb[0] * sg[:, None]
+        da = ops.gemm_tn(du, x, taps=k, lin=Lin, lout=Lout, stride=stride, pad=pad, mode=mode, n1=r, conv_layout=conv)
+        da = da if conv else da[0]
         dm = None
         if ad.m is not None:
-            if sums is not None:                           # (sum dy*y, sum dy) already produced by the GroupNorm backward
-                s1 = sums[0] - bias.detach().float() * sums[1] if bias is not None else sums[0]
-            else:
-                s1 = ops.wcolsum(dy, y, None, B_, Lout).sum(0)
-                if bias is not None:
-                    s1 = s1 - bias.detach().float() * ops.colsum(dy, O)
-            dm = (s1 / ad.m.detach().float().reshape(-1)).reshape(ad.m.shape)
+            sm = s0 - bias32 * s1 if bias is not None else s0
+            dm = (sm / ad.m.detach().float().reshape(-1)).reshape(ad.m.shape)
     return da.reshape(ad.a.shape), db.reshape(ad.b.shape), dm
 
 

@@ -406,9 +406,10 @@ _DKIND = {"same": 0, "down": 1, "up": 2}
 
 
 def pack_weight(w: torch.Tensor, dtype: torch.dtype, kind: str = "same", want_fwd: bool = True, want_dgrad: bool = True,
-                fwd: Optional[torch.Tensor] = None, dgrad: Optional[torch.Tensor] = None, row_offset: int = 0):
+                fwd: Optional[torch.Tensor] = None, dgrad: Optional[torch.Tensor] = None, row_offset: int = 0, adapt=None):
     """fp32 (O, I[, k]) master -> (fwd [k][O][I], dgrad [k'][I][O]) GEMM operands in `dtype`, one launch.  With fwd / dgrad
-    given, this weight's rows are written at row_offset of a larger stacked operand (the fused q|kv projection)."""
+    given, this weight's rows are written at row_offset of a larger stacked operand (the fused q|kv projection).
+    adapt = (lora_A, lora_B, g or None, scaling): pack the LoRA / DoRA effective weight g*(w + s*BA) instead of w."""
     assert w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda
     O, I = w.shape[0], w.shape[1]
     k = w.shape[2] if w.dim() == 3 else 1
@@ -427,8 +428,36 @@ def pack_weight(w: torch.Tensor, dtype: torch.dtype, kind: str = "same", want_fw
         assert dgrad.dtype == dtype and dgrad.is_contiguous() and dgrad.shape[0] == kd and dgrad.shape[1] == I
         d_ld, d_ts = dgrad.shape[2], I * dgrad.shape[2]
         pd = dgrad.data_ptr() + row_offset * dgrad.element_size()
-    call("osuf_pack_weight", _p(w), O, I, k, 1 if dtype == torch.bfloat16 else 0, pf, f_ld, f_ts, pd, d_ld, d_ts, _DKIND[kind], _stream())
+    if adapt is not None:
+        a, b, g, scaling = adapt
+        r = a.shape[0]
+        for t in (a, b):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        assert a.numel() == r * I * k and b.numel() == O * r and (g is None or (g.dtype == torch.float32 and g.numel() == O))
+        call("osuf_pack_weight_adapted", _p(w), _p(a), _p(b), _p(g), float(scaling), r, O, I, k, 1 if dtype == torch.bfloat16 else 0,
+             pf, f_ld, f_ts, pd, d_ld, d_ts, _DKIND[kind], _stream())
+    else:
+        call("osuf_pack_weight", _p(w), O, I, k, 1 if dtype == torch.bfloat16 else 0, pf, f_ld, f_ts, pd, d_ld, d_ts, _DKIND[kind], _stream())
     return (fwd if want_fwd else None), (dgrad if want_dgrad else None)
+
+
+def dora_gain(w: torch.Tensor, a: torch.Tensor, b: torch.Tensor, mag: Optional[torch.Tensor], scaling: float):
+    """-> (g (O,), (s g B)^T as [1][r][O] f32, the same in bf16) for the frozen base w (O, I[, k]), lora_A (r, I[, k]), lora_B (O, r[, 1])
+    and the DoRA magnitude (O values) or None (plain LoRA: g = 1)."""
+    for t in (w, a, b):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+    O, I, r = w.shape[0], w.shape[1], a.shape[0]
+    k = w.shape[2] if w.dim() == 3 else 1
+    assert a.numel() == r * I * k and b.numel() == O * r
+    part = None
+    if mag is not None:
+        assert mag.dtype == torch.float32 and mag.is_contiguous() and mag.numel() == O
+        part = torch.empty(((I + 31) // 32, O), dtype=torch.float32, device=w.device)
+    g = torch.empty(O, dtype=torch.float32, device=w.device)
+    t32 = torch.empty((1, r, O), dtype=torch.float32, device=w.device)
+    t16 = torch.empty((1, r, O), dtype=torch.bfloat16, device=w.device)
+    call("osuf_dora_gain", _p(w), _p(a), _p(b), _p(mag), O, I, k, r, float(scaling), _p(part), _p(g), _p(t32), _p(t16), _stream())
+    return g, t32, t16
 
 
 def dora_effective(w: torch.Tensor, a: torch.Tensor, b: torch.Tensor, mag: Optional[torch.Tensor], scaling: float):
@@ -445,6 +474,15 @@ def dora_effective(w: torch.Tensor, a: torch.Tensor, b: torch.Tensor, mag: Optio
     g = torch.empty(O, dtype=torch.float32, device=w.device)
     call("osuf_dora_effective", _p(w), _p(a), _p(b), _p(mag), O, IK, r, float(scaling), _p(weff), _p(g), _stream())
     return weff, g
+
+
+def adapter_finish(tb, sg, db_out, gt, da_out, s0, s1, bias, m, dm_out, O: int, I: int, k: int, r: int, accumulate: bool) -> None:
+    """dB (+)= sg*tb; dA (+)= flipped / transposed gt; dm (+)= (s0 - bias*s1)/m -- see osuf_adapter_finish."""
+    for t in (tb, sg, db_out, gt, da_out, s0, s1, bias, m, dm_out):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda)
+    assert tb.numel() == O * r and db_out.numel() == O * r and gt.numel() == k * I * r and da_out.numel() == r * I * k and sg.numel() == O
+    call("osuf_adapter_finish", _p(tb), _p(sg), _p(db_out), _p(gt), _p(da_out), _p(s0), _p(s1), _p(bias), _p(m), _p(dm_out), O, I, k, r,
+         1 if accumulate else 0, _stream())
 
 
 def cast_f32_bf16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:

@@ -162,6 +162,38 @@ def test_dora_effective_kernel(shape, r, dora):
 
 
 @gpu
+@pytest.mark.parametrize("shape,r,dora", [((40, 24, 3), 8, True), ((64, 2048, 3), 32, True), ((96, 32), 16, True), ((33, 20, 7), 8, False),
+                                          ((70, 50, 3), 16, True)])
+def test_adapted_pack_and_gain_kernels(shape, r, dora):
+    """The training path never forms the fp32 effective weight: osuf_dora_gain + osuf_pack_weight_adapted must give the GEMM
+    operand layouts of the oracle's effective weight (fp32 packs to 1e-6, bf16 packs to one rounding), g, and (s g B)^T."""
+    from osufusion_amd import ops
+    s = 0.5
+    w = torch.from_numpy(uniform_pm("eff.w", shape, 0.3))
+    a, b, m = _adapter_tensors("eff", shape, r, w, dora)
+    ref = LO.effective_weight(w.double(), a.double(), b.double(), m.double() if dora else None, s)
+    ref3 = ref if ref.dim() == 3 else ref.unsqueeze(-1)
+    k = ref3.shape[2]
+    wd, ad_, bd = w.to(DEV), a.to(DEV).contiguous(), b.to(DEV).contiguous()
+    g, t32, t16 = ops.dora_gain(wd, ad_, bd, m.reshape(-1).to(DEV) if dora else None, s)
+    gref = (m.double().reshape(-1) / LO.weight_norm(w.double(), LO.delta_weight(a.double(), b.double(), w.double()), s)) if dora \
+        else torch.ones(shape[0], dtype=torch.float64)
+    assert _rel(g, gref) < 1e-6
+    sgbt = (s * gref[:, None] * b.double().reshape(shape[0], r)).t()
+    assert _rel(t32[0], sgbt) < 1e-6 and _rel(t16[0].float(), sgbt) < 4e-3
+    for dt, tol in ((torch.float32, 1e-6), (torch.bfloat16, 4e-3)):
+        fwd, dgr = ops.pack_weight(wd, dt, "same", adapt=(ad_, bd, g if dora else None, s))
+        assert fwd.shape == (k, shape[0], shape[1]) and dgr.shape == (k, shape[1], shape[0])
+        assert _rel(fwd.float(), ref3.permute(2, 0, 1)) < tol
+        assert _rel(dgr.float(), ref3.flip(2).permute(2, 1, 0)) < tol
+    if k == 3:                                              # Downsample / Upsample operand layouts of an adapted k3 conv
+        for kind in ("down", "up"):
+            want = ops.pack_weight(ref.float().to(DEV).contiguous(), torch.float32, kind)[1]
+            got = ops.pack_weight(wd, torch.float32, kind, adapt=(ad_, bd, g if dora else None, s))[1]
+            assert _rel(got, want) < 1e-6
+
+
+@gpu
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 3e-2)])
 @pytest.mark.parametrize("conv,dora", [(True, True), (True, False), (False, True)])
 def test_adapted_layer_vs_oracle(dtype, tol, conv, dora):
