@@ -1,3 +1,4 @@
+"""Debug helper (not collected by pytest): sampler vs oracle on the tiny golden config; lives under tests/ because it imports oracle/."""
 import json, sys
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch

@@ -1,9 +1,8 @@
-"""Time the HIP log-VQT front end on a song-length waveform (and the fp64 oracle on a short cut, for scale).
+"""Time the HIP log-VQT front end on a song-length waveform.
 usage: python tools/bench_vqt.py [seconds_of_audio]"""
 import sys
 import time
 
-import numpy as np
 import torch
 
 sys.path.insert(0, ".")
@@ -36,15 +35,6 @@ def main():
     A.log_vqt(y)                                          # host waveform: includes the PCIe upload
     torch.cuda.synchronize()
     print(f"from a host waveform (upload included): {(time.perf_counter() - t0) * 1e3:.2f} ms")
-    try:
-        from oracle import vqt_oracle as VO
-        cut = y[: 10 * A.SR].numpy()
-        t0 = time.perf_counter()
-        VO.vqt(cut)
-        dt = time.perf_counter() - t0
-        print(f"oracle (numpy fp64, 1 core) on 10 s: {dt:.2f} s -> {10 / dt:.1f}x real time")
-    except ImportError:
-        pass
 
 
 if __name__ == "__main__":
