@@ -1,0 +1,88 @@
+"""Parity at BASELINE.json's full size: the 343.5 M-parameter UNet (dim_h=256) on B=32 sequences of L=4096 -- the very shapes
+bench.py times (N=4096 attention, 256x256 GEMM tiles, split wgrads).  The oracle cannot run 32 samples in seconds, so:
+  * samples of a batch are independent in this model (GroupNorm(1, C), per-sample attention), hence two samples picked out of the
+    full fp32-mode batch are compared with the oracle run on each of them alone (1e-3 rel-L2, north_star's bound);
+  * the bf16 training loss and its 343.5 M gradients at B=32 must be the mean of the same quantities over its four B=8 shards
+    (linearity of the mean-reduced loss in the batch; the shards take different tile / split plans than the full batch).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import unet_oracle as O
+
+B, L, DIM_H = 32, 4096, 256
+
+
+def report(name, **vals):
+    """Append achieved errors to gpurun_out/parity_metrics.jsonl (quoted in DESIGN.md)."""
+    import json
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_metrics.jsonl", "a") as f:
+        f.write(json.dumps({"test": name, **{k: float(v) for k, v in vals.items()}}) + "\n")
+
+
+@pytest.fixture(scope="module")
+def full():
+    from osufusion_amd.models.diffusion import OsuFusion
+    torch.manual_seed(0)
+    model = OsuFusion(DIM_H)
+    with torch.no_grad():
+        model.unet.final_conv.weight.normal_(0.0, 0.02)            # the reference zero-inits the head (unet.py:354): give it life
+    model = model.to("cuda")
+    g = torch.Generator().manual_seed(99)
+    x = (torch.randn(B, 6, L, generator=g) * 0.5).clamp_(-1, 1)
+    a = torch.randn(B, 96, L, generator=g) * 3 - 10
+    c = torch.rand(B, 5, generator=g) * 2 - 1
+    t = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.randn(B, 6, L, generator=g)
+    return model, x, a, c, t, noise
+
+
+def test_full_size_forward_samples_vs_oracle(full):
+    import osufusion_amd as oa
+    model, x, a, c, t, _ = full
+    with torch.no_grad(), oa.forced_compute_dtype(torch.float32):
+        got = model.unet(x.cuda(), a.cuda(), t.cuda(), c.cuda()).cpu()
+    assert got.shape == (B, 6, L) and torch.isfinite(got).all()
+    p = {k: v.detach().float().cpu() for k, v in model.unet.state_dict().items()}
+    cfg = O.UNetConfig(dim_h=DIM_H)
+    for i in (0, 21):
+        with torch.no_grad():
+            ref = O.unet_forward(p, cfg, x[i:i + 1], a[i:i + 1], t[i:i + 1], c[i:i + 1])
+        err = ((got[i:i + 1] - ref).norm() / ref.norm()).item()
+        report("full_size_forward_vs_oracle", sample=i, rel_l2=err)
+        assert err < 1e-3, (i, err)
+
+
+def test_full_size_bf16_loss_and_gradients_are_the_mean_over_shards(full):
+    import osufusion_amd as oa
+    from osufusion_amd import functional as Fn
+    from osufusion_amd.train import Trainer
+    model, x, a, c, t, noise = full
+    x, a, c, t, noise = (v.cuda() for v in (x, a, c, t, noise))
+    try:
+        trainer = Trainer(model, compute_dtype=torch.bfloat16)
+
+        def run(sl):
+            trainer.flat.zero_grad()
+            with oa.forced_compute_dtype(torch.bfloat16):
+                loss = model.loss_with(x[sl], a[sl], c[sl], noise[sl], t[sl], cond_drop_prob=0.0)
+                loss.backward()
+            return loss.detach().double(), trainer.flat.grad.detach().clone()
+
+        loss_full, g_full = run(slice(0, B))
+        assert torch.isfinite(loss_full) and torch.isfinite(g_full).all() and g_full.abs().max() > 0
+        loss_sum, g_sum = 0.0, torch.zeros_like(g_full)
+        for s in range(0, B, 8):
+            ls, gs = run(slice(s, s + 8))
+            loss_sum, g_sum = loss_sum + ls, g_sum + gs
+        loss_mean, g_mean = loss_sum / 4, g_sum / 4
+        assert abs(loss_full - loss_mean) / abs(loss_mean) < 1e-3
+        rel = ((g_full - g_mean).double().norm() / g_mean.double().norm()).item()
+        report("full_size_shard_linearity", loss_rel=abs(loss_full - loss_mean) / abs(loss_mean), grad_rel_l2=rel)
+        assert rel < 1e-2, rel                                      # bf16 attention / atomics-order noise; a wrong split plan is O(1)
+    finally:
+        Fn.enable_direct_grads(False)
