@@ -86,3 +86,33 @@ def test_full_size_bf16_loss_and_gradients_are_the_mean_over_shards(full):
         assert rel < 1e-2, rel                                      # bf16 attention / atomics-order noise; a wrong split plan is O(1)
     finally:
         Fn.enable_direct_grads(False)
+
+
+def test_full_size_fresh_dora_adapters_leave_the_denoiser_unchanged(full):
+    """Idempotence at full size (runs last: it wraps the shared model in place).  peft zero-inits lora_B and DoRA starts its
+    magnitude at ||W||, so g = 1 and the adapted UNet must reproduce the base UNet up to the rounding of g; one adapted
+    backward at B=8 must then give finite gradients on every adapter tensor and none on the frozen base."""
+    import osufusion_amd as oa
+    from osufusion_amd.modules import lora_layers as LL
+    model, x, a, c, t, noise = full
+    sl = slice(0, 8)
+    xs, as_, cs, ts, ns = (v[sl].cuda() for v in (x, a, c, t, noise))
+    with torch.no_grad(), oa.forced_compute_dtype(torch.float32):      # fp32 mode: in bf16 a 1e-7 change of g re-rolls the rounding
+        base = model.unet(xs, as_, ts, cs).float()                      # noise of ~90 blocks (1.2e-2 rel-L2, the whole-UNet bf16 floor)
+    LL.get_peft_model(model, LL.LoraConfig(r=16, lora_alpha=16, use_dora=True))
+    n_train, n_all = LL.trainable_parameter_counts(model)
+    assert 0 < n_train < 0.03 * n_all
+    with torch.no_grad(), oa.forced_compute_dtype(torch.float32):
+        adapted = model.unet(xs, as_, ts, cs).float()
+    rel = ((adapted - base).norm() / base.norm()).item()
+    report("full_size_fresh_dora_vs_base_fp32", rel_l2=rel)
+    assert rel < 1e-3, rel                                          # attention is bf16 inside the fp32 mode too (floor ~3e-4)
+    for p in model.parameters():                                        # drop what the previous test left in the flat buffer
+        p.grad = None
+    with oa.forced_compute_dtype(torch.bfloat16):
+        model.loss_with(xs, as_, cs, ns, ts, cond_drop_prob=0.0).backward()
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        else:
+            assert p.grad is None or not p.grad.any(), n
