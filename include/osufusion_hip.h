@@ -108,7 +108,12 @@ int osuf_mqa_bwd_dq(const void* q, long ldq, const void* k, long ldk, const void
                     int out_dtype, const float* rope_cos, const float* rope_sin, hipStream_t stream);
 int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
                      const float* lse2, const float* delta, void* dk, void* dv, long lddk, int B, int H, int N, int head_dim,
-                     float scale, int out_dtype, const float* rope_cos, const float* rope_sin, hipStream_t stream);
+                     float scale, int out_dtype, const float* rope_cos, const float* rope_sin, float* workspace, long workspace_bytes,
+                     hipStream_t stream);
+/* Short sequences give the dK/dV kernel few 256-key workgroups (B=32, N=512: 64 on 256 CUs): with a 16-byte-aligned fp32 workspace
+ * of this many bytes (0 = the shape does not need it) the query range is cut into 2 or 4 parts whose partial sums a finishing pass
+ * adds in a fixed order (then scale, RoPE transpose, cast).  workspace NULL / too small: the unsplit kernel runs. */
+long osuf_mqa_bwd_dkv_workspace_bytes(int B, int N);
 
 /* ---- layout / scheduler / optimizer (elementwise.hip) ----------------------------------------------------------
  * replaces: the (B,C,L) <-> (B,L,C) rearranges (modules/unet.py:180,183) at the model boundary, torch.cat (unet.py:500,

@@ -116,6 +116,8 @@ struct AttnArgs {
   const float* rcos; const float* rsin;         // [N][32] RoPE tables: when set, dQ / dK are stored as gradients of the UN-rotated q / k
   int B, H, N;
   float scale;
+  int qsplit;                                   // dK/dV: > 1 = the query range is cut into qsplit parts (short sequences: more workgroups),
+  float* wsk; float* wsv;                       //        per-part partial sums in [qsplit][B*N][64] workspaces, summed by dkv_finish_kernel
 };
 
 // cooperative K/V tile stage: NT threads move one 64-key tile (64 x 128 B of K and of V = 512 + 512 16-B chunks)
@@ -660,7 +662,9 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_pipe_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int nkb = (a.N + 32 * NW - 1) / (32 * NW);
-  const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;
+  const int per_split = (int)gridDim.x / a.qsplit;                 // workgroups of one query part (a multiple of 8)
+  const int part = (int)blockIdx.x / per_split, bid = (int)blockIdx.x - part * per_split;
+  const int xcd = bid & 7, qid = bid >> 3;
   const int b = (qid / nkb) * 8 + xcd;
   const int kb = qid % nkb;
   if (b >= a.B) return;
@@ -668,7 +672,10 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_pipe_kernel(AttnArgs a) {
   const bool kok = key < a.N;
   const float c = a.scale * kLog2e;
   const int nqb = (a.N + 31) >> 5;
-  const int niter = nqb * a.H;
+  const int qb_per = (nqb + a.qsplit - 1) / a.qsplit;
+  const int qb_begin = part * qb_per, qb_end = min(nqb, qb_begin + qb_per);
+  if (qb_begin >= qb_end) return;                                  // uniform per workgroup, before any barrier
+  const int niter = (qb_end - qb_begin) * a.H;
 
   bf16x8 kf[4], vf[4];
   {
@@ -693,7 +700,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_pipe_kernel(AttnArgs a) {
   const long lld = tid < 256 ? a.ldq : a.lddo;
   const int lds_dst = (tid < 256 ? 0 : 4096) + tile_off(lrow, lchunk * 16);
   u32x4 rt; float rs = 0.f;
-  int ih = 0, ipb = 0;                                            // (head, query block) of the next stage to load
+  int ih = 0, ipb = qb_begin;                                     // (head, query block) of the next stage to load
   auto load_stage = [&]() {
     const int qrow = ipb * 32 + lrow;
     u32x4 z = {0u, 0u, 0u, 0u};
@@ -814,10 +821,40 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_pipe_kernel(AttnArgs a) {
     if (it + 1 < niter) iter(it + 1, sB, sC, sA, s1, dp1, s0, dp0);
     slot = sC;
   }
-  if (kok) {
+  if (kok && a.qsplit > 1) {                                       // this part's partial sums, plain 16-byte stores (atomics measured
+    const long prow = ((long)part * a.B + b) * a.N + key;          // as slow as the iterations the split saves: 38 G atomics/s)
+    store_grad_row(a.wsk + prow * D, dk, 1.f, nullptr, nullptr, lh);
+    store_grad_row(a.wsv + prow * D, dv, 1.f, nullptr, nullptr, lh);
+  } else if (kok) {
     store_grad(a.dk, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dk, a.scale, a.rcos, a.rsin, key, lh);
     store_grad(a.dv, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dv, 1.f, nullptr, nullptr, key, lh);
   }
+}
+
+// second half of the query-split dK/dV path: sum the parts (fixed order), scale, un-rotate (RoPE backward, as store_grad_row), cast
+template <typename TO>
+__global__ __launch_bounds__(256) void dkv_finish_kernel(const float* __restrict__ wsk, const float* __restrict__ wsv, int parts, TO* dk, TO* dv,
+                                                         long ld, long M, int N, float scale, const float* __restrict__ rcos,
+                                                         const float* __restrict__ rsin) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;           // one thread per (row, d < 32)
+  if (idx >= M * 32) return;
+  const long m = idx >> 5;
+  const int d = (int)(idx & 31), n = (int)(m % N);
+  float k1 = 0.f, k2 = 0.f, v1 = 0.f, v2 = 0.f;
+  for (int p = 0; p < parts; ++p) {
+    const long o = ((long)p * M + m) * D + d;
+    k1 += wsk[o]; k2 += wsk[o + 32]; v1 += wsv[o]; v2 += wsv[o + 32];
+  }
+  k1 *= scale; k2 *= scale;
+  if (rcos) {
+    const float cs = rcos[(long)n * 32 + d], sn = rsin[(long)n * 32 + d];
+    const float a1 = k1 * cs + k2 * sn, a2 = k2 * cs - k1 * sn;
+    k1 = a1; k2 = a2;
+  }
+  ElemTraits<TO>::store(dk + m * ld + d, k1);
+  ElemTraits<TO>::store(dk + m * ld + 32 + d, k2);
+  ElemTraits<TO>::store(dv + m * ld + d, v1);
+  ElemTraits<TO>::store(dv + m * ld + 32 + d, v2);
 }
 
 // delta[b][h][n] = sum_d dO[b,n,h,d] * O[b,n,h,d]   (8 lanes per (row, head), 8 elements each)
@@ -948,7 +985,7 @@ static int fill_bwd_args(AttnArgs& a, const void* q, long ldq, const void* k, lo
   a = AttnArgs{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
   a.lse2 = const_cast<float*>(lse2); a.dout = (const bf16_t*)dout; a.lddo = lddo; a.delta = delta;
-  a.B = B; a.H = H; a.N = N; a.scale = scale;
+  a.B = B; a.H = H; a.N = N; a.scale = scale; a.qsplit = 1;
   return OSUF_OK;
 }
 
@@ -994,9 +1031,27 @@ extern "C" int osuf_mqa_bwd_dq(const void* q, long ldq, const void* k, long ldk,
 }
 
 // dk, dv: [B*N][lddk] in out_dtype; rope tables as for dq (applied to dk only)
+// query parts of the dK/dV kernel for this shape: short sequences give few 256-key workgroups (B=32, N=512: 64 on 256 CUs)
+static int dkv_qsplit(int B, int N) {
+  static const int forced = getenv("OSUF_ATTN_DKV_QSPLIT") ? atoi(getenv("OSUF_ATTN_DKV_QSPLIT")) : 0;
+  if (forced > 0) return forced;
+  const int blocks = ((N + 255) / 256) * ((B + 7) / 8 * 8);
+  int sp = 1;
+  while (sp < 4 && blocks * sp < 256 && ((N + 31) / 32) / (sp * 2) >= 4) sp *= 2;
+  return sp;
+}
+
+// fp32 workspace that lets osuf_mqa_bwd_dkv split the query range for this shape (0: no split; the call works without it, unsplit)
+extern "C" long osuf_mqa_bwd_dkv_workspace_bytes(int B, int N) {
+  if (B <= 0 || N <= 0 || attn_waves() == 4 || getenv("OSUF_ATTN_NOPIPE") || getenv("OSUF_ATTN_DBG")) return 0;
+  const int sp = dkv_qsplit(B, N);
+  return sp > 1 ? 2L * sp * B * N * D * (long)sizeof(float) : 0;
+}
+
 extern "C" int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
                                 const float* lse2, const float* delta, void* dk, void* dv, long lddk, int B, int H, int N, int head_dim,
-                                float scale, int out_dtype, const float* rope_cos, const float* rope_sin, hipStream_t stream) {
+                                float scale, int out_dtype, const float* rope_cos, const float* rope_sin, float* workspace,
+                                long workspace_bytes, hipStream_t stream) {
   AttnArgs a;
   int rc = fill_bwd_args(a, q, ldq, k, ldk, v, ldv, dout, lddo, lse2, delta, B, H, N, head_dim, scale);
   if (rc) return rc;
@@ -1016,7 +1071,20 @@ extern "C" int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk
     else if (dbg == 4) hipLaunchKernelGGL((mqa_bwd_dkv_kernel<8, 4>), grid, dim3(512), lds, stream, a);
     else if (dbg == 5) hipLaunchKernelGGL((mqa_bwd_dkv_kernel<8, 5>), grid, dim3(512), lds, stream, a);
     else if (getenv("OSUF_ATTN_NOPIPE")) hipLaunchKernelGGL(mqa_bwd_dkv_kernel<8>, grid, dim3(512), lds, stream, a);
-    else hipLaunchKernelGGL(mqa_bwd_dkv_pipe_kernel, grid, dim3(512), 3 * (4096 + 4096 + 256), stream, a);
+    else {
+      const long need = osuf_mqa_bwd_dkv_workspace_bytes(B, N);
+      if (need > 0 && workspace && workspace_bytes >= need && al16(workspace)) {
+        a.qsplit = dkv_qsplit(B, N);
+        a.wsk = workspace; a.wsv = workspace + (long)a.qsplit * B * N * D;
+        hipLaunchKernelGGL(mqa_bwd_dkv_pipe_kernel, dim3(grid.x * a.qsplit), dim3(512), 3 * (4096 + 4096 + 256), stream, a);
+        const long M = (long)B * N;
+        const unsigned fb = (unsigned)((M * 32 + 255) / 256);
+        if (a.g_bf16) hipLaunchKernelGGL(dkv_finish_kernel<bf16_t>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (bf16_t*)dk, (bf16_t*)dv, lddk, M, N, scale, rope_cos, rope_sin);
+        else hipLaunchKernelGGL(dkv_finish_kernel<float>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (float*)dk, (float*)dv, lddk, M, N, scale, rope_cos, rope_sin);
+      } else {
+        hipLaunchKernelGGL(mqa_bwd_dkv_pipe_kernel, grid, dim3(512), 3 * (4096 + 4096 + 256), stream, a);
+      }
+    }
   }
   return osuf_launch_status();
 }

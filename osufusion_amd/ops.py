@@ -293,8 +293,10 @@ def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Ten
     call("osuf_attn_delta", _p(do), ldo_, _p(o), _rows(o)[2], _DT[o.dtype], _p(delta), B, H, N, D, _stream())
     call("osuf_mqa_bwd_dq", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase, W, B, H, N, D, scale, _DT[out_dtype],
          _p(cos), _p(sin), _stream(), meta=N)
+    need = _lib.load().osuf_mqa_bwd_dkv_workspace_bytes(B, N)          # > 0: short sequence, the query range is split
+    ws = _workspace(need, qkv.device) if need > 0 else None
     call("osuf_mqa_bwd_dkv", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase + es * H * D, gbase + es * (H + 1) * D, W,
-         B, H, N, D, scale, _DT[out_dtype], _p(cos), _p(sin), _stream(), meta=N)
+         B, H, N, D, scale, _DT[out_dtype], _p(cos), _p(sin), _p(ws), need if ws is not None else 0, _stream(), meta=N)
     return dqkv
 
 
