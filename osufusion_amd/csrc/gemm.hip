@@ -1436,6 +1436,9 @@ static bool tn_big_plan(int dtype, int M, int N1, int N2, int taps, int* rows_ou
   const int btiles = ((N1 + kBig - 1) / kBig) * ((N2 + kBig - 1) / kBig);
   int sp = (256 + btiles * taps / 2) / (btiles * taps);        // one workgroup per CU: about one round of the 256 CUs
   if (sp < 1) sp = 1;
+  // ... and never a few workgroups MORE than one round: the launch pads sp * btiles to a multiple of 8 per tap, which turned
+  // 85 x 3 = 255 into 264 workgroups -- the last 8 ran alone in a second round and the launch took 130 us instead of 59
+  while (sp > 1 && ((sp * btiles + 7) / 8) * 8 * taps > 256) --sp;
   int rows = (M + sp - 1) / sp;
   rows = ((rows + 63) / 64) * 64;
   *rows_out = rows;
