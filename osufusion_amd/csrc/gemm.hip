@@ -1473,7 +1473,8 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
     gs.dY = dY; gs.X = X; gs.dW = dW; gs.ws = nullptr; gs.es = es; gs.ldy = ldy; gs.ldx = ldx; gs.ldw = ldw; gs.tapstride = tapstride;
     gs.M = M; gs.N1 = N1; gs.N2 = N2; gs.taps = taps; gs.rm = RowMap{Lin, Lout, stride, pad, mode};
     const int tiles_n1 = (N1 + kBig - 1) / kBig;
-    int sp = (512 + tiles_n1 * taps - 1) / (tiles_n1 * taps);          // ~2 workgroups per CU
+    int sp = 512 / (tiles_n1 * taps);                                  // 2 workgroups per CU, and not one workgroup more than that
+    if (sp < 1) sp = 1;                                                // (rounding up gave 171 x 3 = 513: a second round for one block)
     int rows = (M + sp - 1) / sp;
     rows = ((rows + 63) / 64) * 64;
     if (rows < 256) rows = 256;
