@@ -6,7 +6,10 @@
  * citation after "replaces:" is that call site (paths relative to /root/reference/osu_fusion).
  *
  * Conventions
- *   - plain device pointers + sizes + hipStream_t; no allocation, no global state, no host sync, graph-capturable;
+ *   - plain device pointers + sizes + hipStream_t; no allocation, no host sync, graph-capturable.  Nothing is kept between
+ *     calls except the one-time hipFuncSetAttribute registration of kernels that need > 64 KiB of LDS.  Kernel variants are
+ *     chosen per call (`variant` arguments); the GEMM launchers additionally honour the documented A/B environment switches
+ *     OSUF_GEMM_* (read on every call, never cached) -- measurement aids, not configuration;
  *   - return 0 on success, <0 for an argument error (-1 invalid, -2 unsupported), >0 = hipError_t of the launch;
  *   - activations are channels-last rows [B*L][C] ("rows"), C contiguous, row stride `ld*` in ELEMENTS;
  *   - dtype: 0 = fp32 storage (exact-f32 MFMA), 1 = bf16 storage (bf16 MFMA, fp32 accumulate);
@@ -23,6 +26,10 @@ extern "C" {
 
 #define OSUF_DT_F32 0
 #define OSUF_DT_BF16 1
+/* `variant` of the attention-backward entry points: AUTO picks by shape, PLAIN / PIPE force the plain or the software-pipelined kernel */
+#define OSUF_ATTN_AUTO 0
+#define OSUF_ATTN_PLAIN 1
+#define OSUF_ATTN_PIPE 2
 
 int osuf_version(void);
 
@@ -59,6 +66,12 @@ int osuf_colsum(int dtype, const void* Y, long ldy, int M, int N, float* out, hi
 
 /* ---- GroupNorm(1,C) + FiLM + SiLU (norm.hip)    replaces: Block.forward_body (modules/residual.py:75-84) ---- */
 int osuf_gn_finalize(const double* stats, float* mean_rstd, int B, long count, hipStream_t stream);
+/* The same statistics without atomics, from the stored conv output (one extra read of y): per-chunk sums in `partial`
+ * (osuf_gn_stats_workspace_bytes(M, C, L) bytes), added in a fixed order -- identical inputs give identical bits.  Used by the
+ * sampling loop (models/diffusion.py:59-77, inference_gradio.py:128) so that two calls of sample() return the same beatmap;
+ * the training step keeps the statistics fused into the GEMM epilogue (osuf_gemm_nt `stats`, fp32/fp64 atomics). */
+int osuf_gn_stats(int dtype, const void* y, long ldy, double* partial, float* mean_rstd, int M, int C, int L, hipStream_t stream);
+long osuf_gn_stats_workspace_bytes(int M, int C, int L);
 int osuf_gn_apply_fwd(int dtype, const void* y, long ldy, void* h, long ldh, const float* mean_rstd, const float* gamma,
                       const float* beta, const float* scale_shift, int M, int C, int L, hipStream_t stream);
 /* T1234 [B][4][C] fp32 zeroed scratch; S [B][2] scratch; dss [B][2C] (may be NULL); dgamma/dbeta accumulated into; dbias (may be
@@ -79,8 +92,11 @@ int osuf_ln_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, v
 int osuf_rowdot(int dtype, const void* h, long ldh, const float* w, long w_stride, const float* bias, float* out,
                 int M, int C, int L, hipStream_t stream);
 int osuf_softmax_rows(float* p, int B, int L, hipStream_t stream);
+/* osuf_wcolsum: out[b][c] (+)= sum_l w[b][l] * a[b][l][c] (* bmul[b][l][c]).  partial == NULL: row chunks meet by fp32 atomics in a
+ * zero-initialised `out`; partial = B * ceil(L / 64) * C floats: chunk sums are stored and added in chunk order (`out` overwritten,
+ * bit-reproducible -- the sampling loop's path). */
 int osuf_wcolsum(int dtype, const void* a, long lda, const void* bmul, long ldb, const float* w, float* out,
-                 int B, int C, int L, hipStream_t stream);
+                 int B, int C, int L, float* partial, hipStream_t stream);
 int osuf_gate_residual(int dtype, const void* h, long ldh, const float* gate, const void* res, long ldr, void* out, long ldo,
                        int M, int C, int L, hipStream_t stream);
 int osuf_gca_bwd_apply(int dtype, const void* dout, long lddo, const void* h, long ldh, void* dh, long lddh, const float* p,
@@ -105,15 +121,16 @@ int osuf_attn_delta(const void* dout, long lddo, const void* o, long ldo, int o_
  * gradients of the UN-rotated projections (the rotation's transpose rides the epilogue; dv is never rotated). */
 int osuf_mqa_bwd_dq(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
                     const float* lse2, const float* delta, void* dq, long lddq, int B, int H, int N, int head_dim, float scale,
-                    int out_dtype, const float* rope_cos, const float* rope_sin, hipStream_t stream);
+                    int out_dtype, const float* rope_cos, const float* rope_sin, int variant, hipStream_t stream);
 int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
                      const float* lse2, const float* delta, void* dk, void* dv, long lddk, int B, int H, int N, int head_dim,
                      float scale, int out_dtype, const float* rope_cos, const float* rope_sin, float* workspace, long workspace_bytes,
-                     hipStream_t stream);
+                     int qsplit, int variant, hipStream_t stream);
 /* Short sequences give the dK/dV kernel few 256-key workgroups (B=32, N=512: 64 on 256 CUs): with a 16-byte-aligned fp32 workspace
  * of this many bytes (0 = the shape does not need it) the query range is cut into 2 or 4 parts whose partial sums a finishing pass
- * adds in a fixed order (then scale, RoPE transpose, cast).  workspace NULL / too small: the unsplit kernel runs. */
-long osuf_mqa_bwd_dkv_workspace_bytes(int B, int N);
+ * adds in a fixed order (then scale, RoPE transpose, cast).  workspace NULL / too small: the unsplit kernel runs.
+ * qsplit: 0 = the default split of the shape; 1..16 = force that many parts (the same value goes to osuf_mqa_bwd_dkv). */
+long osuf_mqa_bwd_dkv_workspace_bytes(int B, int N, int qsplit);
 
 /* ---- layout / scheduler / optimizer (elementwise.hip) ----------------------------------------------------------
  * replaces: the (B,C,L) <-> (B,L,C) rearranges (modules/unet.py:180,183) at the model boundary, torch.cat (unet.py:500,

@@ -11,12 +11,12 @@ from ctypes import c_double, c_float, c_int, c_long, c_void_p
 from pathlib import Path
 
 _CSRC = Path(__file__).resolve().parent / "csrc"
-# OSUF_HIP_LIB: load another build of the same C ABI (same-box A/B timing of two kernel revisions; tools/ab.sh)
+# OSUF_HIP_LIB: load another build of the same C ABI (same-box A/B timing of two kernel revisions; tools/build_base.sh)
 LIB_PATH = Path(os.environ["OSUF_HIP_LIB"]).resolve() if os.environ.get("OSUF_HIP_LIB") else _CSRC / "libosuf_hip.so"
 
 P, L, I, F = c_void_p, c_long, c_int, c_float
 
-# name -> argtypes (all return int).  Must list every symbol of include/osufusion_hip.h (tests/test_capi.py checks).
+# name -> argtypes (all return int).  Must list every symbol of include/osufusion_hip.h (tests/test_host_logic.py::test_capi_* check).
 SIGNATURES = {
     "osuf_version": [],
     "osuf_gemm_nt": [I, P, L, P, L, L, P, L, P, L, P, L, P, L, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
@@ -30,16 +30,18 @@ SIGNATURES = {
     "osuf_ln_bwd": [I, P, L, P, L, P, L, P, P, P, P, I, I, P],
     "osuf_rowdot": [I, P, L, P, L, P, P, I, I, I, P],
     "osuf_softmax_rows": [P, I, I, P],
-    "osuf_wcolsum": [I, P, L, P, L, P, P, I, I, I, P],
+    "osuf_wcolsum": [I, P, L, P, L, P, P, I, I, I, P, P],
+    "osuf_gn_stats": [I, P, L, P, P, I, I, I, P],
+    "osuf_gn_stats_workspace_bytes": [I, I, I],
     "osuf_gate_residual": [I, P, L, P, P, L, P, L, I, I, I, P],
     "osuf_gca_bwd_apply": [I, P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, P],
     "osuf_rope_cast": [I, P, L, P, L, P, P, I, I, I, I, I, P],
     "osuf_rope_bwd": [I, P, L, P, L, P, P, I, I, I, I, I, P],
     "osuf_mqa_fwd": [P, L, P, L, P, L, P, L, I, P, I, I, I, I, F, P],
     "osuf_attn_delta": [P, L, P, L, I, P, I, I, I, I, P],
-    "osuf_mqa_bwd_dq": [P, L, P, L, P, L, P, L, P, P, P, L, I, I, I, I, F, I, P, P, P],
-    "osuf_mqa_bwd_dkv": [P, L, P, L, P, L, P, L, P, P, P, P, L, I, I, I, I, F, I, P, P, P, L, P],
-    "osuf_mqa_bwd_dkv_workspace_bytes": [I, I],
+    "osuf_mqa_bwd_dq": [P, L, P, L, P, L, P, L, P, P, P, L, I, I, I, I, F, I, P, P, I, P],
+    "osuf_mqa_bwd_dkv": [P, L, P, L, P, L, P, L, P, P, P, P, L, I, I, I, I, F, I, P, P, P, L, I, I, P],
+    "osuf_mqa_bwd_dkv_workspace_bytes": [I, I, I],
     "osuf_ncl_to_rows": [I, P, P, L, I, I, I, I, I, P],
     "osuf_rows_to_ncl": [I, P, L, P, I, I, I, P],
     "osuf_copy2d": [I, P, L, I, P, L, I, I, P],
@@ -88,7 +90,10 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     except OSError as e:
         raise HipExtensionMissing(f"cannot load {LIB_PATH}: {e}") from e
     for name, argtypes in SIGNATURES.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipExtensionMissing(f"{LIB_PATH} does not export {name} (stale or partial build of the C ABI)") from e
         fn.argtypes = argtypes
         fn.restype = c_long if name.endswith("_bytes") else c_int
     _lib = lib

@@ -959,11 +959,6 @@ static inline int ew_grid(long total_threads) {
   return (int)blocks;
 }
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-static int attn_waves() {                        // waves per workgroup (A/B knob OSUF_ATTN_WAVES=4|8; measured round 1 at N=4096:
-  const char* e = getenv("OSUF_ATTN_WAVES");     // 8 waves 814 / 946 / 846 TFLOP/s (fwd / dQ / dKdV) vs 4 waves 730 / 832 / 587)
-  return (e && atoi(e) == 4) ? 4 : 8;
-}
-
 extern "C" int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
                             float* lse2, int B, int H, int N, int head_dim, float scale, hipStream_t stream) {
   if (head_dim != D) return OSUF_EUNSUPPORTED;
@@ -972,8 +967,7 @@ extern "C" int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, co
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
   a.o = o; a.ldo = ldo; a.o_is_f32 = o_dtype == OSUF_DT_F32; a.lse2 = lse2; a.B = B; a.H = H; a.N = N; a.scale = scale;
   const int nvb = ((N + 31) / 32) * H;
-  if (attn_waves() == 4) hipLaunchKernelGGL(mqa_fwd_kernel<4>, dim3((nvb + 3) / 4, B), dim3(256), 32768 + 4 * 4096, stream, a);
-  else hipLaunchKernelGGL(mqa_fwd_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768 + 8 * 4096, stream, a);
+  hipLaunchKernelGGL(mqa_fwd_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768 + 8 * 4096, stream, a);
   return osuf_launch_status();
 }
 
@@ -1004,24 +998,21 @@ extern "C" int osuf_attn_delta(const void* dout, long lddo, const void* o, long 
 }
 
 // dq: [B*N][lddq] in out_dtype, head h at columns h*64; rope_cos / rope_sin ([N][32], or both NULL): store the gradient of the un-rotated q
-static int dq_pipe_min() {
-  static const int v = getenv("OSUF_ATTN_DQ_PIPE_MIN") ? atoi(getenv("OSUF_ATTN_DQ_PIPE_MIN")) : 2048;
-  return v;
-}
-
+// variant: OSUF_ATTN_AUTO picks by shape; _PLAIN / _PIPE force one kernel (parity tests force each on every shape)
 extern "C" int osuf_mqa_bwd_dq(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
                                const float* lse2, const float* delta, void* dq, long lddq, int B, int H, int N, int head_dim, float scale,
-                               int out_dtype, const float* rope_cos, const float* rope_sin, hipStream_t stream) {
+                               int out_dtype, const float* rope_cos, const float* rope_sin, int variant, hipStream_t stream) {
   AttnArgs a;
   int rc = fill_bwd_args(a, q, ldq, k, ldk, v, ldv, dout, lddo, lse2, delta, B, H, N, head_dim, scale);
   if (rc) return rc;
-  if (lddq % 8 || !al16(dq) || (out_dtype != OSUF_DT_F32 && out_dtype != OSUF_DT_BF16) || ((rope_cos == nullptr) != (rope_sin == nullptr)))
+  if (lddq % 8 || !al16(dq) || (out_dtype != OSUF_DT_F32 && out_dtype != OSUF_DT_BF16) || ((rope_cos == nullptr) != (rope_sin == nullptr)) ||
+      variant < OSUF_ATTN_AUTO || variant > OSUF_ATTN_PIPE)
     return OSUF_EINVAL;
   a.dq = dq; a.lddq = lddq; a.g_bf16 = out_dtype == OSUF_DT_BF16; a.rcos = rope_cos; a.rsin = rope_sin;
   const int nvb = ((N + 31) / 32) * H;
-  if (attn_waves() == 4) hipLaunchKernelGGL(mqa_bwd_dq_kernel<4>, dim3((nvb + 3) / 4, B), dim3(256), 32768, stream, a);
   // the pipelined kernel (2 waves/SIMD, 256 VGPRs) wins once the key loop is long: +4.5 % at N=4096, +3 % at 2048, -2 % at <= 1024
-  else if (N < dq_pipe_min() || getenv("OSUF_ATTN_NOPIPE")) hipLaunchKernelGGL(mqa_bwd_dq_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768, stream, a);
+  if (variant == OSUF_ATTN_AUTO) variant = N >= 2048 ? OSUF_ATTN_PIPE : OSUF_ATTN_PLAIN;
+  if (variant == OSUF_ATTN_PLAIN) hipLaunchKernelGGL(mqa_bwd_dq_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768, stream, a);
   else {
     static bool once = ((void)hipFuncSetAttribute((const void*)mqa_bwd_dq_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536), true);
     (void)once;
@@ -1032,8 +1023,7 @@ extern "C" int osuf_mqa_bwd_dq(const void* q, long ldq, const void* k, long ldk,
 
 // dk, dv: [B*N][lddk] in out_dtype; rope tables as for dq (applied to dk only)
 // query parts of the dK/dV kernel for this shape: short sequences give few 256-key workgroups (B=32, N=512: 64 on 256 CUs)
-static int dkv_qsplit(int B, int N) {
-  static const int forced = getenv("OSUF_ATTN_DKV_QSPLIT") ? atoi(getenv("OSUF_ATTN_DKV_QSPLIT")) : 0;
+static int dkv_qsplit(int B, int N, int forced) {
   if (forced > 0) return forced;
   const int blocks = ((N + 255) / 256) * ((B + 7) / 8 * 8);
   int sp = 1;
@@ -1042,49 +1032,41 @@ static int dkv_qsplit(int B, int N) {
 }
 
 // fp32 workspace that lets osuf_mqa_bwd_dkv split the query range for this shape (0: no split; the call works without it, unsplit)
-extern "C" long osuf_mqa_bwd_dkv_workspace_bytes(int B, int N) {
-  if (B <= 0 || N <= 0 || attn_waves() == 4 || getenv("OSUF_ATTN_NOPIPE") || getenv("OSUF_ATTN_DBG")) return 0;
-  const int sp = dkv_qsplit(B, N);
+// qsplit: 0 = the split this shape gets by default, > 0 = force that many parts (tests)
+extern "C" long osuf_mqa_bwd_dkv_workspace_bytes(int B, int N, int qsplit) {
+  if (B <= 0 || N <= 0 || qsplit < 0 || qsplit > 16) return 0;
+  const int sp = dkv_qsplit(B, N, qsplit);
   return sp > 1 ? 2L * sp * B * N * D * (long)sizeof(float) : 0;
 }
 
 extern "C" int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
                                 const float* lse2, const float* delta, void* dk, void* dv, long lddk, int B, int H, int N, int head_dim,
                                 float scale, int out_dtype, const float* rope_cos, const float* rope_sin, float* workspace,
-                                long workspace_bytes, hipStream_t stream) {
+                                long workspace_bytes, int qsplit, int variant, hipStream_t stream) {
   AttnArgs a;
   int rc = fill_bwd_args(a, q, ldq, k, ldk, v, ldv, dout, lddo, lse2, delta, B, H, N, head_dim, scale);
   if (rc) return rc;
   if (lddk % 8 || !al16(dk) || !al16(dv) || (out_dtype != OSUF_DT_F32 && out_dtype != OSUF_DT_BF16) ||
-      ((rope_cos == nullptr) != (rope_sin == nullptr)))
+      ((rope_cos == nullptr) != (rope_sin == nullptr)) || variant < OSUF_ATTN_AUTO || variant > OSUF_ATTN_PIPE || qsplit < 0 || qsplit > 16)
     return OSUF_EINVAL;
   a.dk = dk; a.dv = dv; a.lddk = lddk; a.g_bf16 = out_dtype == OSUF_DT_BF16; a.rcos = rope_cos; a.rsin = rope_sin;
   const int b8 = (B + 7) / 8 * 8;
-  if (attn_waves() == 4) hipLaunchKernelGGL(mqa_bwd_dkv_kernel<4>, dim3(((N + 127) / 128) * b8), dim3(256), 2 * (4096 + 4096 + 256), stream, a);
-  else {
-    static const int dbg = getenv("OSUF_ATTN_DBG") ? atoi(getenv("OSUF_ATTN_DBG")) : 0;
-    const dim3 grid(((N + 255) / 256) * b8);
-    const int lds = 2 * (4096 + 4096 + 256);
-    if (dbg == 1) hipLaunchKernelGGL((mqa_bwd_dkv_kernel<8, 1>), grid, dim3(512), lds, stream, a);
-    else if (dbg == 2) hipLaunchKernelGGL((mqa_bwd_dkv_kernel<8, 2>), grid, dim3(512), lds, stream, a);
-    else if (dbg == 3) hipLaunchKernelGGL((mqa_bwd_dkv_kernel<8, 3>), grid, dim3(512), lds, stream, a);
-    else if (dbg == 4) hipLaunchKernelGGL((mqa_bwd_dkv_kernel<8, 4>), grid, dim3(512), lds, stream, a);
-    else if (dbg == 5) hipLaunchKernelGGL((mqa_bwd_dkv_kernel<8, 5>), grid, dim3(512), lds, stream, a);
-    else if (getenv("OSUF_ATTN_NOPIPE")) hipLaunchKernelGGL(mqa_bwd_dkv_kernel<8>, grid, dim3(512), lds, stream, a);
-    else {
-      const long need = osuf_mqa_bwd_dkv_workspace_bytes(B, N);
-      if (need > 0 && workspace && workspace_bytes >= need && al16(workspace)) {
-        a.qsplit = dkv_qsplit(B, N);
-        a.wsk = workspace; a.wsv = workspace + (long)a.qsplit * B * N * D;
-        hipLaunchKernelGGL(mqa_bwd_dkv_pipe_kernel, dim3(grid.x * a.qsplit), dim3(512), 3 * (4096 + 4096 + 256), stream, a);
-        const long M = (long)B * N;
-        const unsigned fb = (unsigned)((M * 32 + 255) / 256);
-        if (a.g_bf16) hipLaunchKernelGGL(dkv_finish_kernel<bf16_t>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (bf16_t*)dk, (bf16_t*)dv, lddk, M, N, scale, rope_cos, rope_sin);
-        else hipLaunchKernelGGL(dkv_finish_kernel<float>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (float*)dk, (float*)dv, lddk, M, N, scale, rope_cos, rope_sin);
-      } else {
-        hipLaunchKernelGGL(mqa_bwd_dkv_pipe_kernel, grid, dim3(512), 3 * (4096 + 4096 + 256), stream, a);
-      }
-    }
+  const dim3 grid(((N + 255) / 256) * b8);
+  if (variant == OSUF_ATTN_PLAIN) {
+    hipLaunchKernelGGL(mqa_bwd_dkv_kernel<8>, grid, dim3(512), 2 * (4096 + 4096 + 256), stream, a);
+    return osuf_launch_status();
+  }
+  const long need = osuf_mqa_bwd_dkv_workspace_bytes(B, N, qsplit);
+  if (need > 0 && workspace && workspace_bytes >= need && al16(workspace)) {
+    a.qsplit = dkv_qsplit(B, N, qsplit);
+    a.wsk = workspace; a.wsv = workspace + (long)a.qsplit * B * N * D;
+    hipLaunchKernelGGL(mqa_bwd_dkv_pipe_kernel, dim3(grid.x * a.qsplit), dim3(512), 3 * (4096 + 4096 + 256), stream, a);
+    const long M = (long)B * N;
+    const unsigned fb = (unsigned)((M * 32 + 255) / 256);
+    if (a.g_bf16) hipLaunchKernelGGL(dkv_finish_kernel<bf16_t>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (bf16_t*)dk, (bf16_t*)dv, lddk, M, N, scale, rope_cos, rope_sin);
+    else hipLaunchKernelGGL(dkv_finish_kernel<float>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (float*)dk, (float*)dv, lddk, M, N, scale, rope_cos, rope_sin);
+  } else {
+    hipLaunchKernelGGL(mqa_bwd_dkv_pipe_kernel, grid, dim3(512), 3 * (4096 + 4096 + 256), stream, a);
   }
   return osuf_launch_status();
 }

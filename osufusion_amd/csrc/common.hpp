@@ -5,6 +5,10 @@
 
 #define OSUF_DT_F32 0
 #define OSUF_DT_BF16 1
+// kernel choice of the attention-backward entry points (per call; nothing is read from the environment)
+#define OSUF_ATTN_AUTO 0
+#define OSUF_ATTN_PLAIN 1
+#define OSUF_ATTN_PIPE 2
 
 typedef uint16_t bf16_t;                                   // raw bf16 bits in HBM
 typedef __attribute__((ext_vector_type(4))) float f32x4;

@@ -588,7 +588,8 @@ extern "C" int osuf_adapter_finish(const float* tb, const float* sg, float* dB, 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Clock probe (tools/clock_probe.py): every wave runs `iters` x 8 independent v_mfma_f32_32x32x16_bf16 back to back (mode 1) or
+// Clock probe (tools/clock_probe.py): every wave runs `iters` x 8 independent v_mfma_f32_32x32x16_bf16 back to back (mode 1; mode 2: 16 x
+// v_mfma_f32_16x16x32_bf16, the same FLOPs) or
 // the same number of v_fma_f32 (mode 0) and reports shader-clock cycles (s_memtime) and 100 MHz wall ticks (s_memrealtime):
 // the frequency the chip actually sustains under a matrix-core load, i.e. what "fraction of the 2.4 GHz peak" can mean.
 // ------------------------------------------------------------------------------------------------------
@@ -597,7 +598,12 @@ __global__ __launch_bounds__(256) void clock_probe_kernel(int iters, int mode, l
   f32x16 acc[8];
   for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   bf8 av, bv;
-  for (int i = 0; i < 8; ++i) { av[i] = (__bf16)(0.001f * (threadIdx.x + i)); bv[i] = (__bf16)(0.002f * (threadIdx.x + 2 * i)); }
+  for (int i = 0; i < 8; ++i) {                           // pseudo-random operands in [-1, 1): zero / constant data reads a higher clock
+    uint32_t h = (threadIdx.x * 8u + i + blockIdx.x * 2048u) * 2654435761u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    av[i] = (__bf16)((float)(int)(h & 0xFFFF) * (1.f / 32768.f) - 1.f);
+    bv[i] = (__bf16)((float)(int)(h >> 16) * (1.f / 32768.f) - 1.f);
+  }
   float f = threadIdx.x * 1e-3f;
   const long c0 = __builtin_readcyclecounter();
   const long t0 = wall_clock64();
@@ -606,6 +612,14 @@ __global__ __launch_bounds__(256) void clock_probe_kernel(int iters, int mode, l
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);
     }
+  } else if (mode == 2) {                                 // the same FLOPs per iteration as mode 1 on the 16x16x32 shape
+    f32x4 a4[16];
+    for (int i = 0; i < 16; ++i) for (int r = 0; r < 4; ++r) a4[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, a4[i], 0, 0, 0);
+    }
+    for (int i = 0; i < 16; ++i) f += a4[i][0];
   } else {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll

@@ -1379,7 +1379,7 @@ extern "C" int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, l
     hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  static const bool noskinny = getenv("OSUF_GEMM_NOSKINNY") != nullptr;
+  const bool noskinny = getenv("OSUF_GEMM_NOSKINNY") != nullptr;
   if (!noskinny && dtype == OSUF_DT_BF16 && N <= 32 && N % 8 == 0 && ldc % 8 == 0 && M >= 4096 && !C2 && !R && !U && !bias && !rscale && !stats &&
       act == 0) {
     const int lds_sk = 2 * kSkStage;
@@ -1388,7 +1388,7 @@ extern "C" int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, l
     hipLaunchKernelGGL(gemm_nt_skinny_kernel, dim3((M + kBig - 1) / kBig), dim3(512), lds_sk, stream, g);
     return osuf_launch_status();
   }
-  static const bool regstage = getenv("OSUF_GEMM_REGSTAGE") != nullptr;      // A/B switches for profiling only
+  const bool regstage = getenv("OSUF_GEMM_REGSTAGE") != nullptr;      // A/B switches for profiling only
   // 256^2 tiles once they fill most of the 256 CUs; OSUF_GEMM_BIG_MIN_TILES overrides the threshold (tests force 1, "off" = never)
   const char* bigenv = getenv("OSUF_GEMM_BIG_MIN_TILES");
   const long min_tiles = bigenv ? atol(bigenv) : 192;
@@ -1409,7 +1409,7 @@ extern "C" int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, l
       big_attr = true;
     }
     const long tm = (M + kBig - 1) / kBig, tn = (N + kBig - 1) / kBig;
-    static const int dbg = getenv("OSUF_GEMM_DBG") ? atoi(getenv("OSUF_GEMM_DBG")) : 0;
+    const int dbg = getenv("OSUF_GEMM_DBG") ? atoi(getenv("OSUF_GEMM_DBG")) : 0;
     const dim3 grid_big((int)(((tm + 7) / 8) * 8 * tn));
     if (dbg == 1) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 1>), grid_big, dim3(512), lds_big, stream, g);
     else if (dbg == 2) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 2>), grid_big, dim3(512), lds_big, stream, g);
@@ -1431,7 +1431,7 @@ extern "C" int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, l
 static bool tn_big_plan(int dtype, int M, int N1, int N2, int taps, int* rows_out, int* splits_out) {
   const char* bigenv = getenv("OSUF_GEMM_BIG_MIN_TILES");
   const bool forced = bigenv && atol(bigenv) == 1, off = bigenv && atol(bigenv) <= 0;
-  static const int lo = getenv("OSUF_TN_BIG_MIN_N") ? atoi(getenv("OSUF_TN_BIG_MIN_N")) : 64;
+  const int lo = getenv("OSUF_TN_BIG_MIN_N") ? atoi(getenv("OSUF_TN_BIG_MIN_N")) : 64;
   if (dtype != OSUF_DT_BF16 || off || !(forced || (N1 >= lo && N2 >= lo && (N1 >= 192 || N2 >= 192)))) return false;
   const int btiles = ((N1 + kBig - 1) / kBig) * ((N2 + kBig - 1) / kBig);
   int sp = (256 + btiles * taps / 2) / (btiles * taps);        // one workgroup per CU: about one round of the 256 CUs
@@ -1467,7 +1467,7 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
   if (N1 % epc || N2 % epc || ldy % epc || ldx % epc) return OSUF_EINVAL;
   if (!aligned16(dY) || !aligned16(X)) return OSUF_EINVAL;
   const int bkm = dtype == OSUF_DT_BF16 ? 64 : 32;
-  static const bool noskinny = getenv("OSUF_GEMM_NOSKINNY") != nullptr;
+  const bool noskinny = getenv("OSUF_GEMM_NOSKINNY") != nullptr;
   if (!noskinny && splits <= 0 && dtype == OSUF_DT_BF16 && N2 <= 32 && M >= 4096) {
     WgradArgs gs;
     gs.dY = dY; gs.X = X; gs.dW = dW; gs.ws = nullptr; gs.es = es; gs.ldy = ldy; gs.ldx = ldx; gs.ldw = ldw; gs.tapstride = tapstride;

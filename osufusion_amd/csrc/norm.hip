@@ -32,6 +32,51 @@ __global__ void gn_finalize_kernel(const double* stats, float* mr, int B, double
   mr[2 * b + 1] = (float)(1.0 / sqrt(var + (double)kEps));
 }
 
+// Statistics without atomics (osuf_gn_stats; the sampler's bit-reproducible path): stage 1, grid (row chunks, samples) -- every
+// thread sums its elements in a fixed order, lanes / waves are combined by shuffles and a fixed-order LDS pass, and the chunk's
+// (sum, sum of squares) goes to part[b][chunk][2]; stage 2 adds a sample's chunks in index order.  Same inputs, same bits.
+__device__ __forceinline__ double group_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* y, long ldy, double* part, int C, int L, int rows_per_block, int nchunk) {
+  const int chunks = C >> 3;
+  const int b = blockIdx.y;
+  const ColGeom cg = col_geom(chunks);
+  const int ch = threadIdx.x % cg.cp, rl = threadIdx.x / cg.cp;
+  const int n_begin = blockIdx.x * rows_per_block, n_end = min(L, n_begin + rows_per_block);
+  float s1 = 0.f, s2 = 0.f;
+  if (rl < cg.rp) {
+    for (int n = n_begin + rl; n < n_end; n += cg.rp) {
+      float v[8];
+      load8(y + ((long)b * L + n) * ldy + ch * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
+    }
+  }
+  const double d1 = group_sum_f64((double)s1), d2 = group_sum_f64((double)s2);
+  __shared__ double red[4][2];
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = d1; red[threadIdx.x >> 6][1] = d2; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int w = threadIdx.x;
+    part[((long)b * nchunk + blockIdx.x) * 2 + w] = ((red[0][w] + red[1][w]) + red[2][w]) + red[3][w];
+  }
+}
+__global__ void gn_finalize_parts_kernel(const double* part, float* mr, int B, int nchunk, double inv_count) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < nchunk; ++i) { s1 += part[((long)b * nchunk + i) * 2]; s2 += part[((long)b * nchunk + i) * 2 + 1]; }
+  double mean = s1 * inv_count;
+  double var = s2 * inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  mr[2 * b] = (float)mean;
+  mr[2 * b + 1] = (float)(1.0 / sqrt(var + (double)kEps));
+}
+
 // h = silu( ((y-mean)*rstd*gamma + beta) * (1+scale) + shift );  ss = [B][2C] (scale | shift) or null
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const T* y, long ldy, T* h, long ldh, const float* mr,
@@ -422,7 +467,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* p, int L) {
 //   pooled   = wsum(p, h)          dgate = wsum(null, dout*h)          dwk_b = wsum(dlogit, h)
 template <typename T>
 __global__ __launch_bounds__(256) void wcolsum_kernel(const T* a, long lda, const T* bmul, long ldb, const float* w, float* out,
-                                                      int C, int L, int rows_per_block) {
+                                                      int C, int L, int rows_per_block, float* part) {
   const int chunks = C >> 3;
   const int b = blockIdx.y;
   const ColGeom cg = col_geom(chunks);
@@ -456,8 +501,17 @@ __global__ __launch_bounds__(256) void wcolsum_kernel(const T* a, long lda, cons
   for (int cc = threadIdx.x; cc < C; cc += blockDim.x) {
     float s = 0.f;
     for (int r = 0; r < cg.rp; ++r) s += red[r * C + cc];
-    atomic_add_f32(out + (long)b * C + cc, s);
+    if (part) part[((long)b * gridDim.x + blockIdx.x) * C + cc] = s;      // reproducible path: summed in chunk order below
+    else atomic_add_f32(out + (long)b * C + cc, s);
   }
+}
+// out[b][c] = sum over a sample's row chunks, in chunk order, of the wcolsum partials (no atomics)
+__global__ __launch_bounds__(256) void colsum_parts_kernel(const float* part, float* out, int C, int nchunk) {
+  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int i = 0; i < nchunk; ++i) s += part[((long)b * nchunk + i) * C + c];
+  out[(long)b * C + c] = s;
 }
 
 // out = h * gate[b][:] + res        (res may be null: out = h * gate)
@@ -569,6 +623,20 @@ extern "C" int osuf_gn_finalize(const double* stats, float* mr, int B, long coun
   return osuf_launch_status();
 }
 
+extern "C" long osuf_gn_stats_workspace_bytes(int M, int C, int L) {
+  if (M <= 0 || L <= 0 || M % L || C <= 0 || C % 8 || C > 2048) return 0;
+  const int rpb = (256 / (C / 8)) * 8;
+  return (long)(M / L) * ((L + rpb - 1) / rpb) * 2 * (long)sizeof(double);
+}
+// mean / rstd of GroupNorm(1, C) over each sample of y, by two fixed-order reduction stages (bit-reproducible; one extra read of y)
+extern "C" int osuf_gn_stats(int dtype, const void* y, long ldy, double* partial, float* mr, int M, int C, int L, hipStream_t stream) {
+  if (bad_c(C) || M <= 0 || L <= 0 || M % L || ldy % 8 || !partial) return OSUF_EINVAL;
+  const int rpb = (256 / (C / 8)) * 8, nchunk = (L + rpb - 1) / rpb, B = M / L;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nchunk, B), dim3(256), 0, stream, (const T*)y, ldy, partial, C, L, rpb, nchunk));
+  hipLaunchKernelGGL(gn_finalize_parts_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, partial, mr, B, nchunk, 1.0 / ((double)L * C));
+  return osuf_launch_status();
+}
+
 extern "C" int osuf_gn_apply_fwd(int dtype, const void* y, long ldy, void* h, long ldh, const float* mr, const float* gamma,
                                  const float* beta, const float* ss, int M, int C, int L, hipStream_t stream) {
   if (bad_c(C) || M <= 0 || L <= 0 || M % L || ldy % 8 || ldh % 8) return OSUF_EINVAL;
@@ -642,14 +710,18 @@ extern "C" int osuf_softmax_rows(float* p, int B, int L, hipStream_t stream) {
 }
 
 // out [B][C] fp32 is accumulated into (zero it first)
+// partial (NULL, or B * ceil(L / 64) * C floats): with it the row chunks' sums are stored and added in chunk order by a second
+// kernel -- `out` is then overwritten (no zero-init needed) and bit-reproducible; without it they meet by fp32 atomics in `out`
 extern "C" int osuf_wcolsum(int dtype, const void* a, long lda, const void* bmul, long ldb, const float* w, float* out,
-                            int B, int C, int L, hipStream_t stream) {
+                            int B, int C, int L, float* partial, hipStream_t stream) {
   if (bad_c(C) || B <= 0 || L <= 0 || lda % 8 || (bmul && ldb % 8)) return OSUF_EINVAL;
   const int rp = 256 / (C / 8);
   const int rows_per_block = 64;
+  const int nchunk = (L + rows_per_block - 1) / rows_per_block;
   const size_t lds = (size_t)rp * C * sizeof(float);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(wcolsum_kernel<T>, dim3((L + rows_per_block - 1) / rows_per_block, B), dim3(256), lds, stream,
-                                       (const T*)a, lda, (const T*)bmul, ldb, w, out, C, L, rows_per_block));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(wcolsum_kernel<T>, dim3(nchunk, B), dim3(256), lds, stream,
+                                       (const T*)a, lda, (const T*)bmul, ldb, w, out, C, L, rows_per_block, partial));
+  if (partial) hipLaunchKernelGGL(colsum_parts_kernel, dim3((C + 255) / 256, B), dim3(256), 0, stream, partial, out, C, nchunk);
   return osuf_launch_status();
 }
 

@@ -10,6 +10,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import ops
+from .tracing import scope
 
 _WEIGHT_EPOCH = 0          # bumped by the fused optimizer (it writes parameters through raw pointers)
 
@@ -299,6 +300,11 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with scope({"up": "Upsample (backward)", "down": "Downsample (backward)"}.get(ctx.kind, "Conv (backward)")):
+            return ConvFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = _rc(dy)
         dx = conv_dgrad(dy, w, ctx.cache, ctx.kind, x.shape[1], vp=ctx.vp) if ctx.needs_input_grad[0] else None
@@ -377,13 +383,14 @@ class BlockFn(torch.autograd.Function):
     def forward(ctx, x, w, bias, gamma, beta, ss, cache, adapter=None, la=None, lb=None, lm=None):
         B, L, _ = x.shape
         C = w.shape[0]
-        stats = torch.zeros((B, 2), dtype=torch.float64, device=x.device)
+        repro = ops.reproducible()                         # sampler: statistics by fixed-order reductions, not epilogue atomics
+        stats = None if repro else torch.zeros((B, 2), dtype=torch.float64, device=x.device)
         if adapter is not None:
             weff, _ = adapter.effective()
             y = conv_forward(x, weff, bias, cache, "same", ("dora", *adapter.params), stats=stats)
         else:
             y = conv_forward(x, w, bias, cache, "same", None, stats=stats)
-        mr = ops.gn_finalize(stats, L * C)
+        mr = ops.gn_stats(y, L) if repro else ops.gn_finalize(stats, L * C)
         ssc = ss.contiguous() if ss is not None else None
         h = ops.gn_apply(y, mr, gamma, beta, ssc, L)
         ctx.save_for_backward(x, w, y, mr, gamma, beta, ssc if ssc is not None else mr)
@@ -393,6 +400,11 @@ class BlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dh):
+        with scope("Residual's Block (backward)"):
+            return BlockFn._backward(ctx, dh)
+
+    @staticmethod
+    def _backward(ctx, dh):
         x, w, y, mr, gamma, beta, ss = ctx.saved_tensors
         ss = ss if ctx.has_ss else None
         L = x.shape[1]
@@ -460,6 +472,11 @@ class GCAPoolFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpooled):
+        with scope("GlobalContext (backward)"):
+            return GCAPoolFn._backward(ctx, dpooled)
+
+    @staticmethod
+    def _backward(ctx, dpooled):
         h, wkv, p, pooled = ctx.saved_tensors
         B, L, C = h.shape
         dpooled = dpooled.contiguous().float()
@@ -561,7 +578,7 @@ _ROPE_TABLES: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
 
 def rope_tables(n: int, dim: int, scale_base: int, device, theta: float = 10000.0):
     """cos/sin tables [n][dim/2] in fp32, built exactly as attention.py:24-47 does for an fp32 q (on the host)."""
-    key = (n, dim, scale_base, str(device))
+    key = (n, dim, scale_base, float(theta), str(device))
     hit = _ROPE_TABLES.get(key)
     if hit is None:
         inv_freq = 1.0 / (theta ** (torch.arange(0, dim, 2).float() / dim))
@@ -610,6 +627,11 @@ class AttentionFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        with scope("Attention (backward)"):
+            return AttentionFn._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
         x, nw, mr, xn, wq, wkv, wo, qkv_r, o, lse = ctx.saved_tensors
         H, D, scale_base, scale = ctx.geom
         cache = ctx.cache

@@ -90,6 +90,10 @@ class OsuFusion(nn.Module):
         self.cond_drop_prob = cond_drop_prob
         self._full_bf16 = False
         self.use_hip_graph = False       # capture one DDIM step (2B-batched CFG forward + fused step kernel) in a hipGraph
+        # GroupNorm statistics / GlobalContext pooling by fixed-order reductions while sampling: the same (a, c, x) gives the same
+        # beatmap bit for bit, eager or graph-replayed (costs one extra read of each conv output; False = the training kernels)
+        self.reproducible_sampling = True
+        self.stop_after: Optional[int] = None
 
     def set_full_bf16(self) -> None:
         """diffusion.py:56-57 casts the UNet weights to bf16; here the fp32 masters are kept and every kernel computes in
@@ -103,7 +107,12 @@ class OsuFusion(nn.Module):
     def sample(self, a: torch.Tensor, c: torch.Tensor, x: Optional[torch.Tensor] = None, cond_scale: float = 7.0) -> torch.Tensor:
         """diffusion.py:59-77.  Same outputs, restructured: the audio code is computed once (it does not depend on t or x),
         the conditional and null branches of classifier-free guidance run as one batch of 2B, and the guidance combine is
-        fused into the DDIM-step kernel."""
+        fused into the DDIM-step kernel.  (Attribute `stop_after`, None by default and absent from the reference: return the
+        iterate after that many of the sampling_timesteps steps -- lets tests check single steps of a long schedule.)"""
+        with ops.reproducible_mode(self.reproducible_sampling):
+            return self._sample(a, c, x, cond_scale, self.stop_after)
+
+    def _sample(self, a, c, x, cond_scale, stop_after):
         (b, _, n), device = a.shape, a.device
         rt.require_gpu(a)
         if x is None:
@@ -124,6 +133,9 @@ class OsuFusion(nn.Module):
             else:
                 ce = unet.embed_cond(c, keep)
             steps = self.scheduler.timesteps.tolist()
+            ratio = self.scheduler.num_train_timesteps // self.scheduler.num_inference_steps
+            if stop_after is not None:
+                steps = steps[:stop_after]
             nb = 2 * b if cfg else b
             coef_table = torch.tensor([[self.scheduler.step_coefficients(t)] * b for t in steps], dtype=torch.float32, device=device)
             t_table = torch.tensor([[t] * nb for t in steps], dtype=torch.int64, device=device)

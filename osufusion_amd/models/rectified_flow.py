@@ -47,7 +47,11 @@ class OsuFusion(nn.Module):
     @torch.inference_mode()
     def sample(self, a: torch.Tensor, c: torch.Tensor, x: Optional[torch.Tensor] = None, cond_scale: float = 2.0) -> torch.Tensor:
         """rectified_flow.py:57-79.  Same restructuring as the DDIM sampler: audio code computed once, conditional + null
-        branches as one batch of 2B; 2 * (S - 1) UNet evaluations."""
+        branches as one batch of 2B; 2 * (S - 1) UNet evaluations.  Bit-reproducible (ops.reproducible_mode), as the DDIM sampler."""
+        with ops.reproducible_mode(True):
+            return self._sample(a, c, x, cond_scale)
+
+    def _sample(self, a, c, x, cond_scale):
         (b, _, n), device = a.shape, a.device
         rt.require_gpu(a)
         if x is None:

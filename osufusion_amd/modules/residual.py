@@ -12,6 +12,7 @@ import torch.nn.functional as F  # noqa: N812
 from .. import functional as Fn
 from .. import ops
 from .. import runtime as rt
+from ..tracing import scope
 
 
 class GlobalContext(nn.Module):
@@ -30,10 +31,11 @@ class GlobalContext(nn.Module):
 
     def gate_from_rows(self, h: torch.Tensor, link=None) -> torch.Tensor:
         """rows (B, L, C) -> gate fp32 (B, C_out).  link: functional.GateLink shared with the gate * h consumer."""
-        pooled = Fn.GCAPoolFn.apply(h, self.to_k.weight, self.to_k.bias, link)
-        l0, l2 = self.layers[0], self.layers[2]
-        z = rt.small_linear(pooled, l0.weight, l0.bias)
-        return rt.small_linear(z, l2.weight, l2.bias, in_act=ops.ACT_SILU, out_act=ops.ACT_SIGMOID)
+        with scope("GlobalContext"):                       # the reference's record_function scope (residual.py:35)
+            pooled = Fn.GCAPoolFn.apply(h, self.to_k.weight, self.to_k.bias, link)
+            l0, l2 = self.layers[0], self.layers[2]
+            z = rt.small_linear(pooled, l0.weight, l0.bias)
+            return rt.small_linear(z, l2.weight, l2.bias, in_act=ops.ACT_SILU, out_act=ops.ACT_SIGMOID)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         h = rt.to_rows(x, rt.compute_dtype(self.to_k.weight.dtype))
@@ -54,7 +56,8 @@ class Block(nn.Module):
 
     def forward_rows(self, x: torch.Tensor, ss: Optional[torch.Tensor]) -> torch.Tensor:
         extra = self.proj.adapter_inputs() if hasattr(self.proj, "adapter_inputs") else ()      # lora_layers.LoraConv1d
-        return Fn.BlockFn.apply(x, self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias, ss, self._cache, *extra)
+        with scope("Residual's Block"):                    # residual.py:86
+            return Fn.BlockFn.apply(x, self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias, ss, self._cache, *extra)
 
     def forward(self, x: torch.Tensor, scale_shift: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
         rows = rt.to_rows(x, rt.compute_dtype(self.proj.weight.dtype))
@@ -102,4 +105,7 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x: torch.Tensor, t: Optional[torch.Tensor] = None, c: Optional[torch.Tensor] = None) -> torch.Tensor:
         rows = rt.to_rows(x, rt.compute_dtype(self.block1.proj.weight.dtype))
-        return rt.to_logical(self.forward_rows(rows, t, c))
+        try:
+            return rt.to_logical(self.forward_rows(rows, t, c))
+        finally:
+            rt.clear_shared_cat()                          # stand-alone use: nothing else will drop the memoised cat(t, c)

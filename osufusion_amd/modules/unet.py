@@ -14,14 +14,17 @@ from torch.utils.checkpoint import checkpoint
 from .. import functional as Fn
 from .. import ops
 from .. import runtime as rt
+from ..tracing import scope
 from .residual import ResidualBlock
 from .utils import prob_mask_like
 
 
 def zero_init(module: nn.Module) -> nn.Module:
-    nn.init.zeros_(module.weight)
-    if module.bias is not None:
-        nn.init.zeros_(module.bias)
+    """unet.py:18-23: weight and bias of `module` set to zero (the reference starts final_conv this way, unet.py:354)."""
+    with torch.no_grad():
+        for tensor in (module.weight, module.bias):
+            if tensor is not None:
+                tensor.zero_()
     return module
 
 
@@ -34,11 +37,12 @@ class SinusoidalPositionEmbedding(nn.Module):
         self.theta = theta
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        half_dim = self.dim // 2
-        emb = math.log(self.theta) / (half_dim - 1)
-        emb = torch.exp(torch.arange(half_dim, device=x.device) * -emb)
-        emb = x[:, None] * emb[None, :]
-        return torch.cat([emb.sin(), emb.cos()], dim=-1)
+        """(B,) timesteps -> (B, dim) = [sin(t f_i) | cos(t f_i)], f_i = theta^(-i / (dim/2 - 1)): the divisor is half_dim - 1
+        (unet.py:35), and an int64 t is promoted to fp32 by the product."""
+        n_freq = self.dim // 2
+        freqs = torch.exp(torch.arange(n_freq, device=x.device) * (-math.log(self.theta) / (n_freq - 1)))
+        angles = x.unsqueeze(1) * freqs.unsqueeze(0)
+        return torch.cat((torch.sin(angles), torch.cos(angles)), dim=1)
 
 
 class CrossEmbedLayer(nn.Module):
@@ -98,7 +102,8 @@ class Upsample(nn.Module):
         self._cache = Fn.PackCache()
 
     def forward_rows(self, x: torch.Tensor) -> torch.Tensor:
-        return Fn.ConvFn.apply(x, self.conv.weight, self.conv.bias, self._cache, "up")
+        with scope("Upsample"):                            # the reference's record_function scope (unet.py:72), as a roctx range
+            return Fn.ConvFn.apply(x, self.conv.weight, self.conv.bias, self._cache, "up")
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return rt.to_logical(self.forward_rows(rt.to_rows(x, rt.compute_dtype(self.conv.weight.dtype))))
@@ -113,7 +118,8 @@ class Downsample(nn.Module):
         self._cache = Fn.PackCache()
 
     def forward_rows(self, x: torch.Tensor) -> torch.Tensor:
-        return Fn.ConvFn.apply(x, self.conv.weight, self.conv.bias, self._cache, "down")
+        with scope("Downsample"):                          # unet.py:90
+            return Fn.ConvFn.apply(x, self.conv.weight, self.conv.bias, self._cache, "down")
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return rt.to_logical(self.forward_rows(rt.to_rows(x, rt.compute_dtype(self.conv.weight.dtype))))
@@ -164,8 +170,9 @@ class Attention(nn.Module):
             aq, qa, qb, qm = self.to_q.adapter_inputs() if hasattr(self.to_q, "adapter_inputs") else none4
             akv, ka, kb, km = self.to_kv.adapter_inputs() if hasattr(self.to_kv, "adapter_inputs") else none4
             extra = (aq, akv, qa, qb, qm, ka, kb, km)
-        return Fn.AttentionFn.apply(x, self.norm.weight, self.norm.bias, self.to_q.weight, self.to_kv.weight, self.to_out.weight,
-                                    self.to_out.bias, self._cache, self.heads, self.dim_head, self.context_len, *extra)
+        with scope("Attention"):                           # unet.py:144
+            return Fn.AttentionFn.apply(x, self.norm.weight, self.norm.bias, self.to_q.weight, self.to_kv.weight, self.to_out.weight,
+                                        self.to_out.bias, self._cache, self.heads, self.dim_head, self.context_len, *extra)
 
 
 class FeedForward(nn.Sequential):
@@ -305,17 +312,21 @@ class UNet(nn.Module):
         self._cf = Fn.PackCache()
 
     def set_gradient_checkpointing(self, value: bool) -> None:
-        for name, module in self.named_modules():
-            if hasattr(module, "gradient_checkpointing"):
-                module.gradient_checkpointing = value
-                print(f"Set gradient checkpointing to {value} for {name}")
+        """unet.py:452-456: switch reentrant activation checkpointing of every UNetBlock (the reference prints one line per
+        block; the same line is kept so logs of the two trainers match)."""
+        blocks = [(n, m) for n, m in self.named_modules() if isinstance(m, UNetBlock)]
+        for name, block in blocks:
+            block.gradient_checkpointing = value
+            print(f"Set gradient checkpointing to {value} for {name}")
 
     def forward_with_cond_scale(self, *args: List, cond_scale: float = 1.0, **kwargs: Dict) -> torch.Tensor:
-        logits = self(*args, **kwargs)
+        """unet.py:458-465, classifier-free guidance: null + (cond - null) * cond_scale with the null branch evaluated at
+        cond_drop_prob=1 (a second full forward, as in the reference; OsuFusion.sample batches the two instead)."""
+        cond = self.forward(*args, **kwargs)
         if cond_scale == 1.0:
-            return logits
-        null_logits = self(*args, **kwargs, cond_drop_prob=1.0)
-        return null_logits + (logits - null_logits) * cond_scale
+            return cond
+        null = self.forward(*args, **{**kwargs, "cond_drop_prob": 1.0})
+        return torch.lerp(null, cond, float(cond_scale))
 
     # -- pieces reused by the sampler (audio code cached across DDIM steps) ------------------------------------
     def encode_audio(self, a: torch.Tensor, pad_len: int, dtype: torch.dtype) -> torch.Tensor:

@@ -59,6 +59,29 @@ class KernelTimer:
 
 _TIMER: Optional[KernelTimer] = None
 
+# Reproducible mode (the sampling loop): GroupNorm statistics and GlobalContext pooling by fixed-order two-stage reductions
+# (osuf_gn_stats, osuf_wcolsum with a partial buffer) instead of the atomics fused into the training step's kernels.
+_REPRODUCIBLE = False
+
+
+def reproducible() -> bool:
+    return _REPRODUCIBLE
+
+
+class reproducible_mode:
+    def __init__(self, flag: bool = True) -> None:
+        self.flag = bool(flag)
+
+    def __enter__(self):
+        global _REPRODUCIBLE
+        self.prev, _REPRODUCIBLE = _REPRODUCIBLE, self.flag
+        return self
+
+    def __exit__(self, *exc):
+        global _REPRODUCIBLE
+        _REPRODUCIBLE = self.prev
+        return False
+
 
 def set_kernel_timer(t: Optional[KernelTimer]) -> None:
     global _TIMER
@@ -168,6 +191,17 @@ def gn_finalize(stats: torch.Tensor, count: int) -> torch.Tensor:
     return mr
 
 
+def gn_stats(y: torch.Tensor, L: int) -> torch.Tensor:
+    """(mean, rstd) per sample of GroupNorm(1, C) over rows y, by fixed-order reductions (bit-reproducible)."""
+    M, C, ld = _rows(y)
+    B = M // L
+    need = _lib.load().osuf_gn_stats_workspace_bytes(M, C, L)
+    part = torch.empty(max(need // 8, 1), dtype=torch.float64, device=y.device)
+    mr = torch.empty((B, 2), dtype=torch.float32, device=y.device)
+    call("osuf_gn_stats", dt_of(y), _p(y), ld, _p(part), _p(mr), M, C, L, _stream())
+    return mr
+
+
 def gn_apply(y: torch.Tensor, mr: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ss: Optional[torch.Tensor], L: int) -> torch.Tensor:
     M, C, ld = _rows(y)
     h = torch.empty(y.shape, dtype=y.dtype, device=y.device)
@@ -229,8 +263,13 @@ def softmax_rows_(p: torch.Tensor, B: int, L: int) -> torch.Tensor:
 
 def wcolsum(a: torch.Tensor, bmul: Optional[torch.Tensor], w: Optional[torch.Tensor], B: int, L: int) -> torch.Tensor:
     M, C, ld = _rows(a)
-    out = torch.zeros((B, C), dtype=torch.float32, device=a.device)
-    call("osuf_wcolsum", dt_of(a), _p(a), ld, _p(bmul), _rows(bmul)[2] if bmul is not None else 0, _p(w), _p(out), B, C, L, _stream())
+    part = None
+    if _REPRODUCIBLE:
+        out = torch.empty((B, C), dtype=torch.float32, device=a.device)
+        part = torch.empty((B, (L + 63) // 64, C), dtype=torch.float32, device=a.device)
+    else:
+        out = torch.zeros((B, C), dtype=torch.float32, device=a.device)
+    call("osuf_wcolsum", dt_of(a), _p(a), ld, _p(bmul), _rows(bmul)[2] if bmul is not None else 0, _p(w), _p(out), B, C, L, _p(part), _stream())
     return out
 
 
@@ -280,8 +319,12 @@ def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.
     return o, lse
 
 
+ATTN_AUTO, ATTN_PLAIN, ATTN_PIPE = 0, 1, 2
+
+
 def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, D: int, scale: float,
-            out_dtype: torch.dtype = torch.float32, cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None) -> torch.Tensor:
+            out_dtype: torch.dtype = torch.float32, cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None,
+            variant: int = ATTN_AUTO, qsplit: int = 0) -> torch.Tensor:
     """Gradients laid out like qkv, [B*N][(H+2)*D], in out_dtype.  With the RoPE tables (N, D/2) the q / k gradients are those of
     the un-rotated projections (the rotation's transpose is applied in the kernels' epilogues)."""
     M, W, ld = _rows(qkv)
@@ -292,11 +335,11 @@ def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Ten
     kp, vp, ldo_ = base + 2 * H * D, base + 2 * (H + 1) * D, _rows(do)[2]
     call("osuf_attn_delta", _p(do), ldo_, _p(o), _rows(o)[2], _DT[o.dtype], _p(delta), B, H, N, D, _stream())
     call("osuf_mqa_bwd_dq", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase, W, B, H, N, D, scale, _DT[out_dtype],
-         _p(cos), _p(sin), _stream(), meta=N)
-    need = _lib.load().osuf_mqa_bwd_dkv_workspace_bytes(B, N)          # > 0: short sequence, the query range is split
+         _p(cos), _p(sin), variant, _stream(), meta=N)
+    need = _lib.load().osuf_mqa_bwd_dkv_workspace_bytes(B, N, qsplit)  # > 0: short sequence (or forced), the query range is split
     ws = _workspace(need, qkv.device) if need > 0 else None
     call("osuf_mqa_bwd_dkv", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase + es * H * D, gbase + es * (H + 1) * D, W,
-         B, H, N, D, scale, _DT[out_dtype], _p(cos), _p(sin), _p(ws), need if ws is not None else 0, _stream(), meta=N)
+         B, H, N, D, scale, _DT[out_dtype], _p(cos), _p(sin), _p(ws), need if ws is not None else 0, qsplit, variant, _stream(), meta=N)
     return dqkv
 
 

@@ -92,7 +92,16 @@ def cast_rows(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return x if x.dtype == dtype else _CastFn.apply(x, dtype)
 
 
-_CAT_MEMO = [None, None, None, None]
+_CAT_MEMO = [None, None, None, None, None]
+
+
+def _version_of(v: Optional[torch.Tensor]) -> int:
+    if v is None:
+        return -1
+    try:
+        return v._version
+    except RuntimeError:                                   # inference tensors keep no version counter (sample() runs under
+        return -2                                          # inference_mode; denoise_rows drops the memo after every forward)
 
 
 def shared_cat(t: Optional[torch.Tensor], c: Optional[torch.Tensor]) -> torch.Tensor:
@@ -101,15 +110,16 @@ def shared_cat(t: Optional[torch.Tensor], c: Optional[torch.Tensor]) -> torch.Te
     node.  The grad mode is part of the key: under reentrant activation checkpointing the first pass runs without grad, and a
     tensor memoised there must not be handed to the blocks outside the checkpointed region (it carries no graph)."""
     mode = torch.is_grad_enabled()
-    if _CAT_MEMO[2] is not None and _CAT_MEMO[0] is t and _CAT_MEMO[1] is c and _CAT_MEMO[3] == mode:
+    ver = (_version_of(t), _version_of(c))                  # an in-place update of t / c (static buffers) is a new value
+    if _CAT_MEMO[2] is not None and _CAT_MEMO[0] is t and _CAT_MEMO[1] is c and _CAT_MEMO[3] == mode and _CAT_MEMO[4] == ver:
         return _CAT_MEMO[2]
     e = torch.cat([v for v in (t, c) if v is not None], dim=-1).float()
-    _CAT_MEMO[0], _CAT_MEMO[1], _CAT_MEMO[2], _CAT_MEMO[3] = t, c, e, mode
+    _CAT_MEMO[0], _CAT_MEMO[1], _CAT_MEMO[2], _CAT_MEMO[3], _CAT_MEMO[4] = t, c, e, mode, ver
     return e
 
 
 def clear_shared_cat() -> None:
-    _CAT_MEMO[0] = _CAT_MEMO[1] = _CAT_MEMO[2] = _CAT_MEMO[3] = None
+    _CAT_MEMO[0] = _CAT_MEMO[1] = _CAT_MEMO[2] = _CAT_MEMO[3] = _CAT_MEMO[4] = None
 
 
 def small_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], in_act: int = 0, out_act: int = 0) -> torch.Tensor:

@@ -4,9 +4,11 @@ MI355X-first choices (nothing here mirrors accelerate/DDP's object model):
   * all parameters live in ONE flat fp32 buffer (and their grads / Adam moments in three more): the optimizer is a single
     HIP kernel launch over 343 M elements, the grad-norm is one reduction, and the data-parallel exchange is a handful of
     large contiguous RCCL all-reduces instead of ~1.2 k per-tensor ops;
-  * one process per GPU; gradients are reduced bucket-by-bucket (reverse-autograd order) as soon as a bucket's last
-    gradient has been accumulated, on RCCL's own stream, overlapping the rest of backward; xGMI is point-to-point so buckets
-    are large (64 MiB default) -- a few big rings, not many small ones;
+  * one process per GPU; gradients are reduced bucket-by-bucket as soon as a bucket's last gradient has been accumulated,
+    asynchronously, overlapping the rest of backward; the flat layout follows the OBSERVED completion order of the first
+    backward, so buckets complete front to back; xGMI is point-to-point so buckets are large (64 MiB default) -- a few big
+    rings, not many small ones.  (Not yet run on more than one physical GPU: the round's box has one; covered by 2-rank
+    gloo tests on CPU and on one GPU.)
   * no host sync in the step: the clip coefficient and the 1/world averaging are a device scalar read by the AdamW kernel.
 """
 from __future__ import annotations
@@ -23,22 +25,19 @@ from . import ops
 
 
 class FlatParameters:
-    """Re-homes every parameter of `module` into one flat fp32 buffer (reverse registration order, so the gradients that
-    autograd produces first sit at the front) and gives each a persistent `.grad` view into a flat gradient buffer."""
+    """Re-homes every parameter of `module` into one flat fp32 buffer and gives each a persistent `.grad` view into a flat
+    gradient buffer.  Initial layout: reverse registration order (a first guess at the order in which backward completes the
+    gradients); `reorder` re-lays the buffers out in an observed completion order."""
 
     def __init__(self, module: nn.Module, align: int = 64) -> None:
         params = [p for p in module.parameters() if p.requires_grad]
         assert all(p.dtype == torch.float32 for p in params), "master parameters are fp32"
+        self.align = align
         self.params: List[nn.Parameter] = list(reversed(params))
         device = self.params[0].device
-        self.offsets: List[int] = []
-        off = 0
-        for p in self.params:
-            self.offsets.append(off)
-            off += (p.numel() + align - 1) // align * align
-        self.numel = off
-        self.data = torch.zeros(off, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        self.offsets, self.numel = self._layout(self.params)
+        self.data = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.numel, dtype=torch.float32, device=device)
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 view = self.data[o:o + p.numel()].view_as(p)
@@ -46,24 +45,75 @@ class FlatParameters:
                 p.data = view
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
 
+    def _layout(self, params):
+        offsets, off = [], 0
+        for p in params:
+            offsets.append(off)
+            off += (p.numel() + self.align - 1) // self.align * self.align
+        return offsets, off
+
     def zero_grad(self) -> None:
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):          # a foreign zero_grad(set_to_none=True) may have dropped the views
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
 
+    def reorder(self, order: List[int], companions=()) -> list:
+        """Lay the buffers out as params[order[0]], params[order[1]], ... (a permutation of the current indices).  The parameter
+        values, the gradients and every companion buffer (Adam moments: same layout as `data`) move with their parameter.
+        Returns the re-laid-out companions."""
+        assert sorted(order) == list(range(len(self.params))), "order must be a permutation of the parameter indices"
+        new_params = [self.params[i] for i in order]
+        new_offsets, numel = self._layout(new_params)
+        assert numel == self.numel
+        moved = []
+        with torch.no_grad():
+            for buf in (self.data, self.grad, *companions):
+                nb = torch.zeros_like(buf)
+                for i, no in zip(order, new_offsets):
+                    n = self.params[i].numel()
+                    nb[no:no + n].copy_(buf[self.offsets[i]:self.offsets[i] + n])
+                moved.append(nb)
+            self.data, self.grad = moved[0], moved[1]
+            for p, o in zip(new_params, new_offsets):
+                p.data = self.data[o:o + p.numel()].view_as(p)
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+        self.params, self.offsets = new_params, new_offsets
+        return moved[2:]
+
 
 class GradReducer:
-    """Bucketed, overlapped gradient all-reduce over the flat gradient buffer (the DDP semantics of trainer.py:264-269,301)."""
+    """Bucketed, overlapped gradient all-reduce over the flat gradient buffer (the DDP semantics of trainer.py:264-269,301).
 
-    def __init__(self, flat: FlatParameters, bucket_mib: float = 64.0, group=None) -> None:
-        self.flat, self.group = flat, group
+    A bucket is a contiguous slice of the flat gradient buffer; it is all-reduced (async, SUM) the moment its last parameter
+    reports a complete gradient -- by the kernels' direct-accumulation path (`param_ready`) or by autograd's
+    post-accumulate-grad hook.  A parameter must report ONCE per backward: a second report (a module applied twice, tied
+    weights) would mean the first one was premature and the bucket may already be on the wire, so it raises; train such models
+    with overlap=False (every bucket is reduced in finish()).  `begin(sync=False)` makes a backward a no-sync micro-step of
+    gradient accumulation (`accelerator.accumulate`, trainer.py:293-295): reports are ignored, nothing is sent."""
+
+    def __init__(self, flat: FlatParameters, bucket_mib: float = 64.0, group=None, overlap: bool = True) -> None:
+        self.flat, self.group, self.bucket_mib, self.overlap = flat, group, bucket_mib, overlap
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        cap = int(bucket_mib * (1 << 20) / 4)
+        self.enabled = self.world > 1
+        self.sync = True                                   # False during no-sync accumulation micro-steps
+        self.handles = []
+        self._seen = set()
+        self.order_log: List[int] = []                     # parameter indices in the order they completed (last backward)
+        self.fired_early: List[int] = []                   # buckets launched from a completion report (before finish())
+        self._hooked = set()
+        self._done = set()
+        self._fresh = True                                 # the next completion report opens a new backward
+        self.rebuild()
+
+    def rebuild(self) -> None:
+        """(Re)compute the buckets from the flat layout (after FlatParameters.reorder)."""
+        flat = self.flat
+        cap = int(self.bucket_mib * (1 << 20) / 4)
         self.bounds: List[List[int]] = []                  # [start, end) element ranges
         self.bucket_of: List[int] = []
         start, cur = 0, 0
-        for i, (p, o) in enumerate(zip(flat.params, flat.offsets)):
+        for i in range(len(flat.params)):
             end = flat.offsets[i + 1] if i + 1 < len(flat.offsets) else flat.numel
             self.bucket_of.append(len(self.bounds))
             cur = end
@@ -77,49 +127,74 @@ class GradReducer:
         for b in self.bucket_of:
             self.expected[b] += 1
         self.pending = list(self.expected)
-        self.handles = []
-        self.enabled = self.world > 1
         self._index = {id(p): i for i, p in enumerate(flat.params)}
+        for p in flat.params:                              # hooks look the index up at fire time: they survive a reorder
+            if id(p) not in self._hooked:
+                p.register_post_accumulate_grad_hook(self._hook)
+                self._hooked.add(id(p))
+
+    def begin(self, sync: bool = True) -> None:
+        """Start of a backward: sync=False = gradient-accumulation micro-step without communication."""
+        self.sync = sync
+        self._open()
+
+    def _open(self) -> None:
         self._seen = set()
-        if self.enabled:
-            for idx, p in enumerate(flat.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(idx))
+        self.order_log = []
+        self.fired_early = []
+        self.pending = list(self.expected)
+        self._fresh = False
 
     def param_ready(self, p) -> None:
         """Called by the kernels' direct-accumulation path (functional.grad_done): the gradient of `p` is complete."""
-        if self.enabled:
-            idx = self._index.get(id(p))
-            if idx is not None:
-                self._ready(idx)
+        idx = self._index.get(id(p))
+        if idx is not None:
+            self._ready(idx)
+
+    def _hook(self, param) -> None:
+        idx = self._index.get(id(param))
+        if idx is not None:
+            self._ready(idx)
 
     def _ready(self, idx: int) -> None:
-        if idx in self._seen:                              # a parameter counts once per step, however its gradient arrived
+        if self._fresh:                                    # first report after a finish(): a new backward (begin() is optional)
+            self._open()
+        if idx in self._seen:
+            if self.enabled and self.sync and self.overlap:
+                raise RuntimeError(
+                    f"parameter #{idx} {tuple(self.flat.params[idx].shape)} reported a complete gradient twice in one backward "
+                    "(module applied twice / tied weights): its bucket may already be in flight -- use Trainer(overlap=False)")
             return
         self._seen.add(idx)
+        self.order_log.append(idx)
+        if not (self.enabled and self.sync and self.overlap):
+            return
         b = self.bucket_of[idx]
         self.pending[b] -= 1
         if self.pending[b] == 0:
-            s, e = self.bounds[b]
-            self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.fired_early.append(b)
+            self._launch(b)
 
-    def _make_hook(self, idx: int):
-        def hook(_param):
-            self._ready(idx)
-        return hook
+    def _launch(self, b: int) -> None:
+        s, e = self.bounds[b]
+        self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self) -> None:
-        """Wait for the in-flight buckets (and reduce any bucket whose hooks did not all fire, e.g. unused parameters)."""
-        if not self.enabled:
-            return
-        for b, left in enumerate(self.pending):
-            if left > 0:
-                s, e = self.bounds[b]
-                self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for h in self.handles:
-            h.wait()
+        """Wait for the in-flight buckets (and reduce any bucket whose parameters did not all report, e.g. unused ones)."""
+        if self.enabled and self.sync:
+            for b, left in enumerate(self.pending):
+                if left > 0 or not self.overlap:
+                    self._launch(b)
+            for h in self.handles:
+                h.wait()
         self.handles = []
         self.pending = list(self.expected)
-        self._seen = set()
+        self._done, self._fresh = set(self._seen), True
+
+    def observed_order(self) -> List[int]:
+        """Parameter indices in the order the last finished backward completed them; never-reported ones follow, in place."""
+        rest = [i for i in range(len(self.flat.params)) if i not in self._done]
+        return list(self.order_log) + rest
 
 
 class FusedAdamW:
@@ -198,24 +273,40 @@ def cosine_warmup_lr(step: int, base_lr: float, warmup: int, total: int, num_cyc
 
 
 class Trainer:
-    """One object per rank: flat parameters, (optional) overlapped RCCL gradient reduction, fused AdamW."""
+    """One object per rank: flat parameters, (optional) overlapped RCCL gradient reduction, fused AdamW.
+
+    gradient_accumulation_steps = k reproduces the reference loop `for _ in range(k): with accelerator.accumulate(model): ...`
+    (trainer.py:293-309): each step() call is one micro-batch; the first k-1 add their gradients into the flat buffer without
+    any communication (no-sync), the k-th also reduces, clips and applies AdamW on the mean over all k * world micro-batches.
+    After the first optimizer step the flat buffers are re-laid out in the order in which that backward completed the
+    gradients (reorder_buckets), so that bucket i is complete -- and on the wire -- before bucket i+1."""
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, weight_decay: float = 1e-2, clip_grad_norm: float = 0.0,
-                 bucket_mib: float = 64.0, compute_dtype: Optional[torch.dtype] = torch.bfloat16) -> None:
+                 bucket_mib: float = 64.0, compute_dtype: Optional[torch.dtype] = torch.bfloat16,
+                 gradient_accumulation_steps: int = 1, overlap: bool = True, reorder_buckets: bool = True) -> None:
+        assert gradient_accumulation_steps >= 1
         self.model = model
         self.flat = FlatParameters(model)
-        self.reducer = GradReducer(self.flat, bucket_mib)
+        self.reducer = GradReducer(self.flat, bucket_mib, overlap=overlap)
         self.opt = FusedAdamW(self.flat, lr=lr, weight_decay=weight_decay)
         self.clip = clip_grad_norm
         self.compute_dtype = compute_dtype
+        self.accum = gradient_accumulation_steps
+        self.micro = 0                                      # micro-batches accumulated since the last optimizer step
+        self._reorder_pending = reorder_buckets
         if self.reducer.enabled:                            # identical replicas (guard; inits are already deterministic)
             dist.broadcast(self.flat.data, src=0)
         Fn.bump_weight_epoch()
         Fn.enable_direct_grads(True, self.reducer.param_ready)
 
     def step(self, x, a, c, noise=None, timesteps=None, orig_len=None):
+        """One micro-batch.  Returns (loss, total_norm): total_norm is the device scalar of the clipped step's gradient norm on
+        the micro-batch that applied the optimizer, None on accumulation-only micro-batches."""
         from .runtime import forced_compute_dtype
-        self.flat.zero_grad()
+        if self.micro == 0:
+            self.flat.zero_grad()
+        last = self.micro + 1 == self.accum
+        self.reducer.begin(sync=last)
         with forced_compute_dtype(self.compute_dtype):
             if noise is None:
                 loss = self.model(x, a, c, orig_len)
@@ -223,8 +314,24 @@ class Trainer:
                 loss = self.model.loss_with(x, a, c, noise, timesteps, orig_len)
             loss.backward()
         self.reducer.finish()
-        total_norm = self.opt.step(grad_scale=1.0 / self.reducer.world, clip_grad_norm=self.clip)
+        self.micro += 1
+        if not last:
+            return loss.detach(), None
+        self.micro = 0
+        total_norm = self.opt.step(grad_scale=1.0 / (self.reducer.world * self.accum), clip_grad_norm=self.clip)
+        if self._reorder_pending:
+            self._reorder_pending = False
+            self.apply_observed_order()
         return loss.detach(), total_norm
+
+    def apply_observed_order(self) -> None:
+        """Re-lay the flat buffers (parameters, gradients, Adam moments) out in the gradient-completion order of the last
+        backward and rebuild the buckets over the new layout."""
+        order = self.reducer.observed_order()
+        if order != list(range(len(order))):
+            self.opt.exp_avg, self.opt.exp_avg_sq = self.flat.reorder(order, (self.opt.exp_avg, self.opt.exp_avg_sq))
+            self.reducer.rebuild()
+            Fn.bump_weight_epoch()                          # parameter storage moved: cached operand packs key on data_ptr
 
     # -- checkpoint.pt in the reference's layout (trainer.py:148-203): resumable by either trainer ------------------------
     def state_dict(self, scheduler_state: Optional[dict] = None) -> dict:

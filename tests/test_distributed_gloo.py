@@ -47,6 +47,58 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _worker_reorder_accum(rank, world, port, out):
+    """Observed-order re-layout, early bucket launches, and a no-sync accumulation micro-step (trainer.py:293-295)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _model()
+        names = {id(p): n for n, p in model.named_parameters()}
+        flat = FlatParameters(model, align=4)
+        red = GradReducer(flat, bucket_mib=0.001)
+        x, y = _data()
+        xs, ys = x.chunk(world)[rank], y.chunk(world)[rank]
+        # backward #1 under the initial layout: record the completion order, then re-lay the buffers out in it
+        flat.zero_grad()
+        red.begin(sync=True)
+        ((model(xs) - ys) ** 2).mean().backward()
+        red.finish()
+        before = {names[id(p)]: (p.detach().clone(), p.grad.clone()) for p in flat.params}
+        order = red.observed_order()
+        assert sorted(order) == list(range(len(flat.params)))
+        companion = flat.data.clone() * 3.0                         # stands for an Adam moment buffer
+        (companion,) = flat.reorder(order, (companion,))
+        red.rebuild()
+        for p, o in zip(flat.params, flat.offsets):                 # values, gradients and companions moved with their parameter
+            v, g = before[names[id(p)]]
+            assert torch.equal(p.detach(), v) and torch.equal(p.grad, g)
+            assert p.data_ptr() == flat.data.data_ptr() + 4 * o and p.grad.data_ptr() == flat.grad.data_ptr() + 4 * o
+            assert torch.equal(companion[o:o + p.numel()].view_as(p), 3.0 * v)
+        # backward #2 under the observed layout: buckets complete front to back, all but (at most) the last fire before finish()
+        flat.zero_grad()
+        red.begin(sync=True)
+        ((model(xs) - ys) ** 2).mean().backward()
+        assert red.order_log == list(range(len(flat.params))), "second backward must complete parameters in layout order"
+        assert red.fired_early == list(range(len(red.bounds)))
+        red.finish()
+        g_sync = {names[id(p)]: p.grad.clone() / world for p in flat.params}
+        # gradient accumulation: micro-step 1 without communication, micro-step 2 reduces the accumulated sum
+        halves = [(xs[:2], ys[:2]), (xs[2:], ys[2:])]
+        flat.zero_grad()
+        red.begin(sync=False)
+        ((model(halves[0][0]) - halves[0][1]) ** 2).mean().backward()
+        red.finish()
+        assert red.fired_early == [] and red.handles == []
+        local_only = flat.grad.clone()
+        red.begin(sync=True)
+        ((model(halves[1][0]) - halves[1][1]) ** 2).mean().backward()
+        red.finish()
+        g_acc = {names[id(p)]: p.grad.clone() / (2 * world) for p in flat.params}
+        out[rank] = (g_sync, g_acc, bool(local_only.abs().sum() > 0))
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -92,3 +144,78 @@ def test_cosine_warmup_schedule():
     assert abs(cosine_warmup_lr(10, 1.0, 10, 100) - 1.0) < 1e-12
     assert abs(cosine_warmup_lr(55, 1.0, 10, 100) - 0.5) < 1e-12
     assert cosine_warmup_lr(100, 1.0, 10, 100) < 1e-12
+
+
+@pytest.mark.timeout(120)
+def test_observed_order_relayout_and_no_sync_accumulation():
+    """The averaged gradient after (a) the observed-order re-layout and (b) one no-sync + one syncing micro-step equals the
+    single-process gradient on the concatenated batch; buckets over the observed layout all fire during backward."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_reorder_accum, args=(world, _free_port(), out), nprocs=world, join=True)
+    model = _model()
+    x, y = _data()
+    ((model(x) - y) ** 2).mean().backward()
+    ref = {n: p.grad for n, p in model.named_parameters()}
+    for r in range(world):
+        g_sync, g_acc, had_local = out[r]
+        assert had_local
+        for n, g in ref.items():
+            assert torch.allclose(g_sync[n], g, rtol=1e-5, atol=1e-7), (r, n)
+            assert torch.allclose(g_acc[n], g, rtol=1e-5, atol=1e-7), (r, n)
+
+
+def _worker_double_report(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # (a) a module applied twice through autograd: the post-accumulate hook fires once, after BOTH uses -- correct as is
+        torch.manual_seed(3)
+        lin = nn.Linear(8, 8)
+        model = nn.Sequential(lin, nn.SiLU(), lin)
+        flat = FlatParameters(model, align=4)
+        red = GradReducer(flat, bucket_mib=0.0001)
+        g = torch.Generator().manual_seed(5 + rank)
+        xs = torch.randn(4, 8, generator=g)
+        flat.zero_grad()
+        red.begin()
+        model(xs).square().mean().backward()
+        red.finish()
+        mine = flat.grad.clone()
+        # (b) the kernels' direct-accumulation path reporting one parameter twice must not pass silently
+        flat.zero_grad()
+        red.begin()
+        red.param_ready(flat.params[0])
+        raised = False
+        try:
+            red.param_ready(flat.params[0])
+        except RuntimeError as e:
+            raised = "twice" in str(e)
+        red.finish()
+        # (c) ... and is accepted without overlap: everything is reduced in finish()
+        red.enabled = False                                        # its hooks stay registered on the parameters: silence it
+        red2 = GradReducer(flat, bucket_mib=0.0001, overlap=False)
+        flat.zero_grad()
+        red2.begin()
+        model(xs).square().mean().backward()
+        red2.param_ready(flat.params[0])
+        red2.param_ready(flat.params[0])
+        assert red2.fired_early == []
+        red2.finish()
+        out[rank] = (mine, raised, flat.grad.clone())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_parameter_reporting_twice_is_refused_when_overlapping():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_double_report, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        mine, raised, no_overlap = out[r]
+        assert raised
+        assert torch.allclose(mine, no_overlap, rtol=1e-6, atol=1e-8)      # both paths: the summed gradient of the shared module
+    assert torch.equal(out[0][0], out[1][0])

@@ -88,6 +88,95 @@ def test_full_size_bf16_loss_and_gradients_are_the_mean_over_shards(full):
         Fn.enable_direct_grads(False)
 
 
+def test_full_size_one_sample_gradient_vs_oracle(full):
+    """The full 343.5 M-parameter UNet on one L=4096 sample: loss and all 1,239 parameter gradients of the HIP train path (direct
+    accumulation into the flat buffer, N=4096 pipelined attention backward, 256^2 split-wgrad plans) against the oracle's
+    autograd (the CPU restatement pinned to the reference's goldens; fp32 + bf16 SDPA, unet.py:125-141, attention.py:87-101)."""
+    import osufusion_amd as oa
+    from oracle import diffusion_oracle as DO
+    from osufusion_amd import functional as Fn
+    from osufusion_amd.train import Trainer
+    model, x, a, c, t, noise = full
+    i = 5
+    xs, as_, cs, ts, ns = (v[i:i + 1] for v in (x, a, c, t, noise))
+    cfg = O.UNetConfig(dim_h=DIM_H)
+    p = {k: v.detach().float().cpu().clone().requires_grad_() for k, v in model.state_dict().items()}
+    loss_ref = DO.training_loss(p, cfg, xs, as_, cs, ns, ts, cond_drop_prob=0.0)
+    loss_ref.backward()
+    gref = {k: v.grad for k, v in p.items()}
+    ref_flat = torch.cat([g.reshape(-1) for g in gref.values()]).double()
+    try:
+        trainer = Trainer(model, compute_dtype=torch.float32, reorder_buckets=False)
+        names = {id(q): n for n, q in model.named_parameters()}
+        for mode, tol_loss, tol_flat, tol_norm_max, tol_norm_med in ((torch.float32, 1e-4, 5e-3, 3e-2, 1e-3),
+                                                                     (torch.bfloat16, 2e-2, 6e-2, 2.5e-1, 3e-2)):
+            trainer.flat.zero_grad()
+            with oa.forced_compute_dtype(mode):
+                loss = model.loss_with(xs.cuda(), as_.cuda(), cs.cuda(), ns.cuda(), ts.cuda(), cond_drop_prob=0.0)
+                loss.backward()
+            got = {names[id(q)]: trainer.flat.grad[o:o + q.numel()].view_as(q).cpu() for q, o in zip(trainer.flat.params, trainer.flat.offsets)}
+            assert set(got) == set(gref) and len(got) == 1239
+            got_flat = torch.cat([got[k].reshape(-1) for k in gref]).double()
+            e_loss = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
+            e_flat = ((got_flat - ref_flat).norm() / ref_flat.norm()).item()
+            rel_norm = torch.tensor([abs(got[k].double().norm().item() - gref[k].double().norm().item()) / (gref[k].double().norm().item() + 1e-30)
+                                     for k in gref])
+            tag = "fp32" if mode == torch.float32 else "bf16"
+            report(f"full_size_gradient_vs_oracle/{tag}", loss_rel=e_loss, flat_grad_rel_l2=e_flat, grad_norm_rel_max=rel_norm.max(),
+                   grad_norm_rel_median=rel_norm.median())
+            assert e_loss < tol_loss, (tag, e_loss)
+            assert e_flat < tol_flat, (tag, e_flat)
+            assert rel_norm.max() < tol_norm_max and rel_norm.median() < tol_norm_med, (tag, rel_norm.max(), rel_norm.median())
+    finally:
+        Fn.enable_direct_grads(False)
+
+
+def test_config4_ddim_step_vs_oracle(full):
+    """BASELINE config 4 (inference_gradio.py:105,128 -> diffusion.py:59-77): B=16, L=8192, S=50, cond_scale 2.  The first DDIM step
+    (t = 980; 2B-batched classifier-free guidance, cached audio code, fused step kernel) is checked for two samples against the
+    oracle's sequential cond / null forwards + scheduler step; the hipGraph-replayed second step must equal the eager one."""
+    import osufusion_amd as oa
+    from oracle import diffusion_oracle as DO
+    model = full[0]
+    Bc, Lc, S, cs = 16, 8192, 50, 2.0
+    g = torch.Generator().manual_seed(404)
+    a = torch.randn(Bc, 96, Lc, generator=g) * 3 - 10
+    c = torch.rand(Bc, 5, generator=g) * 2 - 1
+    x0 = torch.randn(Bc, 6, Lc, generator=g)
+    model.sampling_timesteps = S
+    try:
+        model.stop_after = 1
+        with oa.forced_compute_dtype(torch.float32):
+            got = model.sample(a.cuda(), c.cuda(), x0.cuda(), cond_scale=cs).cpu()
+        assert got.shape == (Bc, 6, Lc) and torch.isfinite(got).all()
+        p = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        cfg = O.UNetConfig(dim_h=DIM_H)
+        acp = DO.ddim_alphas_cumprod()
+        t0 = int(DO.ddim_timesteps(S)[0])
+        for i in (0, 11):
+            tb = torch.full((1,), t0, dtype=torch.int64)
+            with torch.no_grad():
+                cond = O.unet_forward(p, cfg, x0[i:i + 1], a[i:i + 1], tb, c[i:i + 1], cond_drop_prob=0.0, prefix="unet.")
+                null = O.unet_forward(p, cfg, x0[i:i + 1], a[i:i + 1], tb, c[i:i + 1], cond_drop_prob=1.0, prefix="unet.")
+            want = DO.ddim_step(null + (cond - null) * cs, t0, x0[i:i + 1], acp, S)
+            eps_scale = (1 - acp[t0 - 1000 // S]).sqrt().item()               # x_prev = sqrt(a_prev) x0_clamped + eps_scale * eps
+            err = ((got[i:i + 1] - want).norm() / want.norm()).item()
+            report("config4_first_ddim_step_vs_oracle", sample=i, rel_l2=err, eps_scale=eps_scale)
+            assert err < 2e-3, (i, err)                                        # CFG doubles the eps error (s = 2): 2 x the 1e-3 bound
+        # two steps in bf16 (the benchmarked mode): eager == eager, graph == eager
+        model.stop_after = 3
+        with oa.forced_compute_dtype(torch.bfloat16):
+            e1 = model.sample(a.cuda(), c.cuda(), x0.cuda(), cond_scale=cs)
+            e2 = model.sample(a.cuda(), c.cuda(), x0.cuda(), cond_scale=cs)
+            model.use_hip_graph = True
+            g1 = model.sample(a.cuda(), c.cuda(), x0.cuda(), cond_scale=cs)
+        assert torch.equal(e1, e2) and torch.equal(e1, g1)
+    finally:
+        model.stop_after = None
+        model.use_hip_graph = False
+        model.sampling_timesteps = 35
+
+
 def test_full_size_fresh_dora_adapters_leave_the_denoiser_unchanged(full):
     """Idempotence at full size (runs last: it wraps the shared model in place).  peft zero-inits lora_B and DoRA starts its
     magnitude at ||W||, so g = 1 and the adapted UNet must reproduce the base UNet up to the rounding of g; one adapted

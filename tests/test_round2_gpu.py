@@ -1,0 +1,254 @@
+"""GPU parity tests added in round 2 (run with -m gpu on an MI355X), all through the C ABI:
+  * every attention-backward kernel (plain / software-pipelined dQ, plain / pipelined / query-split dK/dV) FORCED on every
+    shape, including the N = 2048 / 4096 shapes the benchmark runs, against autograd of the fp32 formula
+    (attention.py:87-101, unet.py:125-141);
+  * clip_grad_norm_ + AdamW of the train step (trainer.py:305-307) through osuf_sqnorm / osuf_clip_coef / osuf_adamw;
+  * UNet.forward_with_cond_scale (unet.py:458-465), Attend (attention.py:84-101), OsuFusion.set_full_bf16 (diffusion.py:56-57);
+  * the sampler is bit-reproducible, and a hipGraph-replayed step equals the eager one (diffusion.py:59-77).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import osufusion_amd as oa
+    from osufusion_amd import functional as Fn
+    from osufusion_amd import ops
+
+from oracle import diffusion_oracle as DO
+from oracle import unet_oracle as O
+from tests.test_hip_parity import DEV, _build_model, rell2, relmax, report
+
+
+# ---- attention backward: every kernel on every shape ---------------------------------------------------------
+def _attn_case(Bn, N, H, D=64):
+    qkv = torch.randn(Bn, N, (H + 2) * D, device=DEV).to(torch.bfloat16)
+    do = torch.randn(Bn, N, H * D).to(torch.bfloat16)
+    qkv32 = qkv.float().cpu().requires_grad_()
+    q = qkv32[..., : H * D].view(Bn, N, H, D).permute(0, 2, 1, 3)
+    k = qkv32[..., H * D: (H + 1) * D][:, None]
+    v = qkv32[..., (H + 1) * D:][:, None]
+    s = (q @ k.transpose(-1, -2)) * D ** -0.5
+    o_ref = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(Bn, N, H * D)
+    o_ref.backward(do.float())
+    return qkv, do.to(DEV), o_ref.detach(), qkv32.grad
+
+
+@pytest.mark.parametrize("N", [200, 512, 2048, 4096])
+def test_every_attention_backward_kernel_vs_fp32_autograd(N):
+    """N = 2048 / 4096 are the shapes at which the train step picks mqa_bwd_dq_pipe_kernel and the unsplit
+    mqa_bwd_dkv_pipe_kernel; N = 200 forces the pipelined kernels through a ragged last tile; qsplit forces the split path."""
+    H, D = 4, 64
+    Bn = 2 if N <= 512 else 1
+    qkv, do, o_ref, g_ref = _attn_case(Bn, N, H)
+    o, lse = ops.mqa_fwd(qkv, Bn, N, H, D, torch.bfloat16, D ** -0.5)
+    assert rell2(o.float(), o_ref) < 5e-3                              # bf16 P and bf16 output rounding
+    cases = [("auto", ops.ATTN_AUTO, 0), ("plain", ops.ATTN_PLAIN, 0), ("pipe-unsplit", ops.ATTN_PIPE, 1), ("pipe-split2", ops.ATTN_PIPE, 2),
+             ("pipe-split4", ops.ATTN_PIPE, 4)]
+    outs = {}
+    for name, variant, qsplit in cases:
+        dqkv = ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5, variant=variant, qsplit=qsplit)
+        e2, em = rell2(dqkv, g_ref), relmax(dqkv, g_ref)
+        for part, sl in (("dq", slice(0, H * D)), ("dk", slice(H * D, (H + 1) * D)), ("dv", slice((H + 1) * D, (H + 2) * D))):
+            ep = rell2(dqkv[..., sl], g_ref[..., sl])
+            report(f"attn_bwd/N{N}/{name}/{part}", rel_l2=ep)
+            assert ep < 1e-2, (name, part, ep)                         # bf16 P / dS operands, fp32 accumulation
+        assert e2 < 1e-2 and em < 3e-2, (name, e2, em)
+        outs[name] = dqkv
+    # the kernels differ only in schedule / summation order
+    assert rell2(outs["plain"], outs["pipe-unsplit"]) < 2e-3
+    # fused RoPE-transpose epilogue of the pipelined kernels == the stand-alone rope_bwd kernel on their fp32 result
+    cos, sin = Fn.rope_tables(N, D, 2 * N, DEV)
+    for name, variant, qsplit in cases[2:4]:
+        ref_r = ops.rope_bwd(outs[name], torch.bfloat16, cos, sin, N, H + 1, H + 2, D)
+        got_r = ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5, torch.bfloat16, cos, sin, variant=variant, qsplit=qsplit)
+        assert relmax(got_r.float(), ref_r.float()) < 8e-3, name
+
+
+def test_attention_backward_rejects_unknown_variant():
+    qkv = torch.zeros(1, 64, 6 * 64, device=DEV, dtype=torch.bfloat16)
+    o, lse = ops.mqa_fwd(qkv, 1, 64, 4, 64, torch.bfloat16, 0.125)
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        ops.mqa_bwd(qkv, o, o, lse, 1, 64, 4, 64, 0.125, variant=7)
+
+
+# ---- clip + AdamW (trainer.py:305-307) -----------------------------------------------------------------------
+@pytest.mark.parametrize("max_norm", [0.0, 0.05, 1e4])                 # no clipping / clipping active / threshold not reached
+@pytest.mark.parametrize("world", [1, 4])
+def test_clip_and_adamw_match_torch(max_norm, world):
+    from osufusion_amd.train import FlatParameters, FusedAdamW
+    torch.manual_seed(3)
+    model = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Linear(19, 5)).to(DEV)
+    ref = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Linear(19, 5)).to(DEV)
+    ref.load_state_dict(model.state_dict())
+    try:
+        flat = FlatParameters(model, align=4)
+        opt = FusedAdamW(flat, lr=1e-2, weight_decay=1e-2)
+        topt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=1e-2)
+        for step in range(3):
+            gsum = [torch.randn_like(p) * (1.0 + step) for p in ref.parameters()]          # what a SUM all-reduce leaves behind
+            for p, g in zip(model.parameters(), gsum):
+                p.grad.copy_(g)
+            for p, g in zip(ref.parameters(), gsum):
+                p.grad = g / world                                                         # DDP's averaged gradient
+            if max_norm > 0:
+                tn_ref = torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm)
+            else:
+                tn_ref = torch.linalg.vector_norm(torch.stack([p.grad.norm() for p in ref.parameters()]))
+            topt.step()
+            tn = opt.step(grad_scale=1.0 / world, clip_grad_norm=max_norm)
+            assert abs(tn.item() - tn_ref.item()) < 1e-5 * tn_ref.item()
+            for p, q in zip(model.parameters(), ref.parameters()):
+                assert torch.allclose(p, q, rtol=1e-5, atol=1e-6), (step, max_norm, world)
+    finally:
+        Fn.enable_direct_grads(False)
+
+
+# ---- public API pieces without a test in round 1 --------------------------------------------------------------
+def test_forward_with_cond_scale_vs_oracle(golden_dir):
+    """unet.py:458-465: null + (cond - null) * s from two sequential forwards (the sampler batches them; this is the method)."""
+    from osufusion_amd.pattern import synth_inputs
+    meta, cfgd, model = _build_model("unet_tiny", golden_dir)
+    cfg = O.UNetConfig(**cfgd)
+    p = O.make_params(cfg)
+    x, a, c, t, _ = (torch.from_numpy(v) for v in synth_inputs("cfg", 2, 256))
+    with torch.no_grad():
+        cond = O.unet_forward(p, cfg, x, a, t, c, cond_drop_prob=0.0)
+        null = O.unet_forward(p, cfg, x, a, t, c, cond_drop_prob=1.0)
+        for s in (1.0, 2.5):
+            want = cond if s == 1.0 else null + (cond - null) * s
+            with oa.forced_compute_dtype(torch.float32):
+                got = model.unet.forward_with_cond_scale(x.to(DEV), a.to(DEV), t.to(DEV), c.to(DEV), cond_scale=s)
+            e = rell2(got, want)
+            report(f"forward_with_cond_scale/{s}", rel_l2=e)
+            assert e < 1e-3, (s, e)
+
+
+@pytest.mark.parametrize("N", [96, 1000])
+def test_attend_module_vs_sdpa(N):
+    """attention.py:84-101: q, k, v -> bf16, SDPA, back to the input dtype (fp32 in, fp32 out); K/V repeated over heads."""
+    from osufusion_amd.modules.attention import Attend
+    Bn, H, D = 2, 4, 64
+    q = torch.randn(Bn, H, N, D, device=DEV)
+    k1, v1 = torch.randn(Bn, 1, N, D, device=DEV), torch.randn(Bn, 1, N, D, device=DEV)
+    k, v = k1.expand(Bn, H, N, D).contiguous(), v1.expand(Bn, H, N, D).contiguous()      # the GQA repeat of unet.py:135
+    got = Attend()(q, k, v)
+    assert got.dtype == q.dtype and got.shape == q.shape
+    qb, kb, vb = (t.to(torch.bfloat16).float().cpu() for t in (q, k, v))
+    want = F.scaled_dot_product_attention(qb, kb, vb).to(torch.bfloat16).float()
+    assert rell2(got, want) < 5e-3 and relmax(got, want) < 1.5e-2
+    assert torch.equal(got, Attend()(q, k1, v1))                                         # un-repeated single K/V head: same kernel
+    with pytest.raises(NotImplementedError):
+        Attend()(q, k, v, attn_mask=torch.ones(N, N, device=DEV, dtype=torch.bool))
+
+
+def test_set_full_bf16_switches_every_kernel_to_bf16(golden_dir):
+    """diffusion.py:56-57 casts the UNet to bf16; here the masters stay fp32 and all kernels compute in bf16: the output is
+    that of a forced-bf16 run bit for bit, stays within the bf16 bound of the fp32 run, and the parameters keep their dtype."""
+    from osufusion_amd.pattern import synth_inputs
+    meta, cfgd, model = _build_model("unet_tiny", golden_dir)
+    x, a, c, t, noise = (torch.from_numpy(v).to(DEV) for v in synth_inputs("fullbf16", 2, 256))
+    with torch.no_grad():
+        with oa.forced_compute_dtype(torch.float32):
+            y32 = model.unet(x, a, t, c)
+        with oa.forced_compute_dtype(torch.bfloat16):
+            y16 = model.unet(x, a, t, c)
+            l16 = model.loss_with(x, a, c, noise, t, cond_drop_prob=0.0)
+        model.set_full_bf16()
+        ybf = model.loss_with(x, a, c, noise, t, cond_drop_prob=0.0)
+    assert torch.equal(ybf, l16)
+    assert all(p.dtype == torch.float32 for p in model.parameters())
+    assert 1e-5 < rell2(y16, y32) < 2e-2
+
+
+# ---- sampler: reproducible, graph == eager (diffusion.py:59-77, inference_gradio.py:105,128) ------------------------
+@pytest.mark.parametrize("cond_scale", [1.0, 2.0])
+def test_sampler_is_bit_reproducible_and_graph_equals_eager(golden_dir, cond_scale):
+    from osufusion_amd.pattern import synth_inputs
+    meta, cfgd, model = _build_model("unet_tiny", golden_dir)
+    model.sampling_timesteps = 6
+    x, a, c, t, noise = (torch.from_numpy(v).to(DEV) for v in synth_inputs("repro", 3, 256))
+    with oa.forced_compute_dtype(torch.bfloat16):                      # the mode the sampler benchmark runs in
+        s1 = model.sample(a, c, noise.clone(), cond_scale=cond_scale)
+        s2 = model.sample(a, c, noise.clone(), cond_scale=cond_scale)
+        assert torch.isfinite(s1).all() and torch.equal(s1, s2), "two eager calls of sample() must agree bit for bit"
+        model.use_hip_graph = True
+        g1 = model.sample(a, c, noise.clone(), cond_scale=cond_scale)
+        g2 = model.sample(a, c, noise.clone(), cond_scale=cond_scale)
+        model.use_hip_graph = False
+    assert torch.equal(g1, g2) and torch.equal(g1, s1), "hipGraph replay of the step must equal the eager step"
+    # the reproducible kernels are the same arithmetic as the training kernels up to summation order
+    model.reproducible_sampling = False
+    with oa.forced_compute_dtype(torch.float32):
+        model.stop_after = 1
+        fast = model.sample(a, c, noise.clone(), cond_scale=cond_scale)
+        model.reproducible_sampling = True
+        slow = model.sample(a, c, noise.clone(), cond_scale=cond_scale)
+        model.stop_after = None
+    assert rell2(fast, slow) < 1e-3
+
+
+def test_reproducible_reductions_vs_atomic_ones():
+    """osuf_gn_stats (fixed-order) vs the statistics fused into the GEMM epilogue; osuf_wcolsum with / without the partial buffer."""
+    Bn, L, C = 3, 520, 96
+    y = torch.randn(Bn, L, C, device=DEV) * 2 + 0.3
+    for dt in (torch.float32, torch.bfloat16):
+        yy = y.to(dt)
+        mr = ops.gn_stats(yy, L)
+        mean = yy.float().mean(dim=(1, 2))
+        rstd = (yy.float().var(dim=(1, 2), unbiased=False) + 1e-5).rsqrt()
+        assert torch.allclose(mr[:, 0], mean, atol=1e-5) and torch.allclose(mr[:, 1], rstd, rtol=1e-5)
+        assert torch.equal(mr, ops.gn_stats(yy, L))
+        w = torch.rand(Bn * L, device=DEV)
+        want = (yy.float() * w.view(Bn, L, 1)).sum(1)
+        atomic = ops.wcolsum(yy, None, w, Bn, L)
+        with ops.reproducible_mode(True):
+            det = ops.wcolsum(yy, None, w, Bn, L)
+            assert torch.equal(det, ops.wcolsum(yy, None, w, Bn, L))
+        assert relmax(det, want) < 1e-5 and relmax(atomic, want) < 1e-5
+
+
+def test_trainer_gradient_accumulation_and_relayout(golden_dir):
+    """trainer.py:293-309 with gradient_accumulation_steps = 2: two micro-batches of 2 give the gradient (and the clipped AdamW
+    moments) of one batch of 4; the observed-order re-layout after the first optimizer step moves parameters, gradients and Adam
+    moments together and makes the next backward complete its gradients in layout order."""
+    from osufusion_amd.pattern import synth_inputs
+    from osufusion_amd.train import Trainer
+    x, a, c, t, noise = (torch.from_numpy(v).to(DEV) for v in synth_inputs("accum", 4, 256))
+
+    def named(tr, buf):
+        names = {id(p): n for n, p in tr.model.named_parameters()}
+        return {names[id(p)]: buf[o:o + p.numel()].clone() for p, o in zip(tr.flat.params, tr.flat.offsets)}
+
+    try:
+        _, _, m1 = _build_model("unet_tiny", golden_dir)
+        m1.cond_drop_prob = 0.0
+        tr1 = Trainer(m1, lr=1e-3, clip_grad_norm=1.0, compute_dtype=torch.float32, reorder_buckets=False)
+        _, n1 = tr1.step(x, a, c, noise, t)
+        g1, m1st = named(tr1, tr1.flat.grad), named(tr1, tr1.opt.exp_avg)
+        _, _, m2 = _build_model("unet_tiny", golden_dir)
+        m2.cond_drop_prob = 0.0
+        tr2 = Trainer(m2, lr=1e-3, clip_grad_norm=1.0, compute_dtype=torch.float32, gradient_accumulation_steps=2, reorder_buckets=True)
+        first_layout = [id(p) for p in tr2.flat.params]
+        _, n_a = tr2.step(x[:2], a[:2], c[:2], noise[:2], t[:2])
+        assert n_a is None and tr2.opt.step_count == 0                 # accumulation-only micro-batch: no optimizer step
+        _, n2 = tr2.step(x[2:], a[2:], c[2:], noise[2:], t[2:])
+        assert tr2.opt.step_count == 1 and abs(n1.item() - n2.item()) < 2e-3 * n1.item()
+        assert [id(p) for p in tr2.flat.params] != first_layout, "the completion order differs from reverse registration order"
+        g2, m2st = named(tr2, tr2.flat.grad), named(tr2, tr2.opt.exp_avg)
+        for k in g1:
+            assert relmax(g2[k] / 2, g1[k]) < 2e-3 or g1[k].abs().max() < 1e-9, k     # sum of two half-batch means = 2 x full mean
+            assert relmax(m2st[k], m1st[k]) < 2e-3 or m1st[k].abs().max() < 1e-12, k   # Adam moments moved with their parameter
+        for p, o in zip(tr2.flat.params, tr2.flat.offsets):
+            assert p.data_ptr() == tr2.flat.data.data_ptr() + 4 * o and p.grad.data_ptr() == tr2.flat.grad.data_ptr() + 4 * o
+        tr2.step(x[:2], a[:2], c[:2], noise[:2], t[:2])
+        tr2.step(x[2:], a[2:], c[2:], noise[2:], t[2:])
+        assert tr2.reducer.order_log == list(range(len(tr2.flat.params))), "after the re-layout gradients complete in layout order"
+        tr1.step(x, a, c, noise, t)
+        e = rell2(torch.cat([v for v in named(tr2, tr2.flat.grad).values()]) / 2, torch.cat([named(tr1, tr1.flat.grad)[k] for k in named(tr2, tr2.flat.grad)]))
+        assert e < 2e-2, e                                             # second step: same trajectory up to Adam's sign noise on ~0 gradients
+    finally:
+        Fn.enable_direct_grads(False)

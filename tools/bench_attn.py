@@ -24,11 +24,11 @@ for N in ([int(a) for a in sys.argv[1:]] or [4096, 2048, 1024, 512]):
     kp, vp = base + 2 * H * D, base + 2 * (H + 1) * D
     st = torch.cuda.current_stream().cuda_stream
     ops.call("osuf_attn_delta", do.data_ptr(), H * D, o.data_ptr(), H * D, 1, delta.data_ptr(), B, H, N, D, st)
-    need = ops._lib.load().osuf_mqa_bwd_dkv_workspace_bytes(B, N)
+    need = ops._lib.load().osuf_mqa_bwd_dkv_workspace_bytes(B, N, 0)
     ws = torch.empty(max(need, 16) // 4, dtype=torch.float32, device=dev)
     wsp = ws.data_ptr() if need else None
     f = 4.0 * B * H * N * N * D
     t1 = timeit(lambda: ops.mqa_fwd(qkv, B, N, H, D, torch.bfloat16, D ** -0.5))
-    t2 = timeit(lambda: ops.call("osuf_mqa_bwd_dq", base, ld, kp, ld, vp, ld, do.data_ptr(), H * D, lse.data_ptr(), delta.data_ptr(), gbase, W, B, H, N, D, D ** -0.5, 0, None, None, st))
-    t3 = timeit(lambda: ops.call("osuf_mqa_bwd_dkv", base, ld, kp, ld, vp, ld, do.data_ptr(), H * D, lse.data_ptr(), delta.data_ptr(), gbase + 4 * H * D, gbase + 4 * (H + 1) * D, W, B, H, N, D, D ** -0.5, 0, None, None, wsp, need, st))
+    t2 = timeit(lambda: ops.call("osuf_mqa_bwd_dq", base, ld, kp, ld, vp, ld, do.data_ptr(), H * D, lse.data_ptr(), delta.data_ptr(), gbase, W, B, H, N, D, D ** -0.5, 0, None, None, 0, st))
+    t3 = timeit(lambda: ops.call("osuf_mqa_bwd_dkv", base, ld, kp, ld, vp, ld, do.data_ptr(), H * D, lse.data_ptr(), delta.data_ptr(), gbase + 4 * H * D, gbase + 4 * (H + 1) * D, W, B, H, N, D, D ** -0.5, 0, None, None, wsp, need, 0, 0, st))
     print(f"{N:6d} {t1:8.3f} {f / t1 / 1e9:6.0f} | {t2:8.3f} {1.5 * f / t2 / 1e9:6.0f} | {t3:8.3f} {2 * f / t3 / 1e9:6.0f}", flush=True)

@@ -3,7 +3,7 @@ import sys
 sys.path.insert(0, "/root/repo")
 import torch
 from osufusion_amd import ops
-for mode, name in ((1, "MFMA 32x32x16 bf16"), (0, "v_fma_f32")):
+for mode, name in ((1, "MFMA 32x32x16 bf16"), (2, "MFMA 16x16x32 bf16 (16 per iteration)"), (0, "v_fma_f32")):
     for blocks in (256, 1024, 2048):
         out = torch.zeros(2 * blocks, dtype=torch.int64, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
