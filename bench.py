@@ -29,14 +29,23 @@ import torch.distributed as dist  # noqa: E402
 MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 DIM_H, BATCH, LENGTH, HEADS, HEAD_DIM = 256, 32, 4096, 16, 64
 STEP_TFLOP = 125.1                      # 3 x 1,303 GFLOP/sample x 32 (recompute not counted)
-# HBM-side bytes per launch of each attention kernel, mean over the 39 launches of one step at the headline shape, from separate
-# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command (profiles/r01_pmc/bench_{fetch,write}_size_by_kernel.csv);
-# FETCH_SIZE doubled as MI355X_MICROARCH.md "HBM" prescribes for 16-B/lane streams on gfx950.  bench.py cannot run the profiler
-# on itself, so the offline measurement is quoted (algorithmic bytes of the dK/dV kernel over the same mix: 289 MB).  Re-measured
-# after the kernels were software-pipelined, stand-alone at N=4096 (profiles/r01_pmc2/): dK/dV 2 x 287.0 MiB fetched + 64.0 MiB
-# written = 655 MB, i.e. x 0.4423 (the mix's mean N-weight) = 289.7 MB per launch -- unchanged.
-# End of round 1 (scale / RoPE folded into the backward epilogues, profiles/r01_pmc3/): 2 x 280.2 MiB + 64.0 MiB = 655 MB at N=4096 -- unchanged.
-PMC_TRAFFIC_BYTES = {"osuf_mqa_bwd_dkv": 2 * 129.9e6 + 29.7e6, "osuf_mqa_bwd_dq": 2 * 182.0e6 + 237.5e6, "osuf_mqa_fwd": 2 * 133.4e6 + 219.0e6}
+# C-ABI entry point -> (algorithmic, executed) attention FLOPs per launch in units of B*H*N^2*D.  SURVEY.md section 8d counts the
+# backward as 2x the forward (recompute is not work): forward 4; the dQ kernel and the dK/dV kernel 4 + 4 (they EXECUTE 6 + 8: S
+# and dP are recomputed in both); the fused backward sweep is the whole backward, 8 (it executes 10: five products).
+ATTN_UNITS = {"osuf_mqa_fwd": (4.0, 4.0), "osuf_mqa_bwd_dq": (4.0, 6.0), "osuf_mqa_bwd_dkv": (4.0, 8.0), "osuf_mqa_bwd_fused": (8.0, 10.0)}
+TRAFFIC_FILE = ROOT / "profiles" / "attn_hbm_traffic.json"   # HBM-side bytes per launch from rocprofv3 --pmc passes (tools/pmc_traffic.py)
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` (mean over one step's launches at the headline shape) from the committed counter summary:
+    separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md 'HBM' prescribes.  bench.py cannot run the
+    profiler on itself; None when the summary has no row for the kernel that dominates this run."""
+    try:
+        rows = json.loads(TRAFFIC_FILE.read_text())
+    except (OSError, ValueError):
+        return None, None
+    row = rows.get(kernel)
+    return (row["bytes_per_launch"], row.get("source")) if row else (None, None)
 
 
 def synth_batch(rank: int, device, batch: int, length: int):
@@ -79,9 +88,19 @@ def cpu_baseline(model, length: int, threads: int):
         times.append(time.perf_counter() - t0)
         print(f"[bench] cpu_baseline: iteration {it} fwd+bwd {times[-1]:.1f} s", file=sys.stderr, flush=True)
     dt = sum(times[1:]) / len(times[1:])
-    return dict(value=1.0 / (BATCH * dt), unit="denoise-steps/sec (B=32, linear extrapolation from B=1)", cores=threads, kind="port",
+    return dict(value=1.0 / (BATCH * dt), unit="denoise-steps/sec (B=32, linear extrapolation from B=1)", cores=threads, cpu=cpu_model(), kind="port",
                 sample=f"fwd+bwd of the full UNet at B=1, L={length}: {dt:.2f} s/sample (mean of 2 after 1 warm-up; oracle/, "
                        f"fp32 + bf16 SDPA as the reference computes on CPU)")
+
+
+def cpu_model() -> str:
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def host_threads() -> int:
@@ -106,6 +125,8 @@ def main() -> None:
                     help="BASELINE config 5 instead of the headline metric: DoRA rank-R adapters on attn.to_q/to_kv and "
                          "block{1,2}.proj (trainer_peft.py:236-244), base frozen; the reference runs R=32, config 5 says 16")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-fp32-mode", action="store_true", help="skip the extra fp32-compute-mode step (the mode in which the 1e-3 parity bound holds)")
+    ap.add_argument("--attn-bwd", choices=["auto", "pair", "fused"], default="auto", help="attention backward: the dQ + dK/dV kernel pair or the fused sweep")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,6 +155,8 @@ def main() -> None:
         with torch.no_grad():                              # peft zero-inits lora_B: give it life so every adapter gradient is exercised
             for m in LL.lora_modules(model):
                 m.lora_B["default"].weight.normal_(0.0, 0.02)
+    if args.attn_bwd != "auto":
+        ops.ATTN_BWD_DEFAULT = ops.ATTN_FUSED if args.attn_bwd == "fused" else ops.ATTN_AUTO
     trainer = Trainer(model, lr=1e-4, weight_decay=1e-2, clip_grad_norm=1.0, compute_dtype=torch.bfloat16)
     x, a, c, noise, t = synth_batch(rank, device, args.batch, args.length)
 
@@ -148,7 +171,7 @@ def main() -> None:
     for _ in range(args.warmup):
         trainer.step(x, a, c, noise, t)
     sync()
-    prof = ops.KernelTimer(["osuf_mqa_fwd", "osuf_mqa_bwd_dq", "osuf_mqa_bwd_dkv"])
+    prof = ops.KernelTimer(list(ATTN_UNITS))
     ops.set_kernel_timer(prof)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -171,14 +194,20 @@ def main() -> None:
         dom = max(stats, key=lambda k: stats[k]["total_ms"]) if stats else None
         roof = None
         if dom is not None:
-            # per launch: forward 4*B*H*N^2*D; dQ kernel 3 of the 5 backward products = 6*B*H*N^2*D; dK/dV kernel 4 = 8*...
-            per = {"osuf_mqa_fwd": 4.0, "osuf_mqa_bwd_dq": 6.0, "osuf_mqa_bwd_dkv": 8.0}[dom]
-            tf = sum(per * args.batch * HEADS * n * n * HEAD_DIM for n in stats[dom]["sizes"]) / 1e12
-            ach = tf / (stats[dom]["total_ms"] / 1e3)
+            def tflop(name, which):                        # FLOPs of all timed launches of one entry point
+                return sum(ATTN_UNITS[name][which] * args.batch * HEADS * n * n * HEAD_DIM for n in stats[name]["sizes"]) / 1e12
+            sec = stats[dom]["total_ms"] / 1e3
+            ach, exe = tflop(dom, 0) / sec, tflop(dom, 1) / sec
+            traffic, tsrc = pmc_traffic(dom) if full else (None, None)
+            bwd = [k for k in stats if k != "osuf_mqa_fwd"]
+            bwd_ms = sum(stats[k]["total_ms"] for k in bwd)
             roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4), traffic=PMC_TRAFFIC_BYTES.get(dom) if full else None,
-                        traffic_unit="HBM-side bytes per launch (offline rocprofv3 PMC, profiles/r01_pmc/)", launches=stats[dom]["launches"],
+                        frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4), traffic=traffic, traffic_unit="HBM-side bytes per launch", traffic_source=tsrc,
+                        flops="algorithmic (SURVEY 8d: attention backward = 2 x forward, recomputed products not counted)",
+                        executed=round(exe, 1), executed_frac=round(exe / MFMA_BF16_PEAK_TFLOPS, 4), launches=stats[dom]["launches"],
                         mean_launch_ms=round(stats[dom]["total_ms"] / stats[dom]["launches"], 3),
+                        attention_backward=dict(kernels=bwd, ms_per_step=round(bwd_ms / args.steps, 2),
+                                                achieved=round(sum(tflop(k, 0) for k in bwd) / (bwd_ms / 1e3), 1) if bwd_ms else None),
                         step_frac_of_peak=round(STEP_TFLOP / (ms / 1e3) / MFMA_BF16_PEAK_TFLOPS, 4) if full else None,
                         all_kernels_ms_per_step={k: round(v["total_ms"] / args.steps, 2) for k, v in stats.items()})
         metric = "denoise-steps/sec (train fwd+bwd) at B=32 L=4096"
@@ -198,6 +227,18 @@ def main() -> None:
             "loss": round(loss.item(), 5), "grad_norm": round(gnorm.item(), 4),
             "roofline": roof,
         }
+        if world == 1 and not args.no_fp32_mode and not args.lora and full:
+            # the compute mode in which north_star's 1e-3 bound holds (exact-f32 MFMA everywhere, bf16 only where the reference casts):
+            # one warm-up + one timed step, after the timed region; bf16 (timed above) sits at the reference's own autocast distance
+            trainer.compute_dtype = torch.float32
+            trainer.step(x, a, c, noise, t)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            trainer.step(x, a, c, noise, t)
+            torch.cuda.synchronize()
+            out["fp32_mode_ms_per_step"] = round(1e3 * (time.perf_counter() - t1), 1)
+            out["parity_note"] = ("bf16 (timed) is 0.9-1.3e-2 rel-L2 from the fp32 oracle = the oracle's own bf16-vs-fp32 distance; "
+                                  "fp32 mode meets 1e-3 (tests/test_full_size.py)")
         if world == 1 and not args.no_cpu_baseline and not args.lora:
             out["cpu_baseline"] = cpu_baseline(model, args.length, args.cpu_threads or host_threads())
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

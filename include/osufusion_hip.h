@@ -132,6 +132,18 @@ int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk, const voi
  * qsplit: 0 = the default split of the shape; 1..16 = force that many parts (the same value goes to osuf_mqa_bwd_dkv). */
 long osuf_mqa_bwd_dkv_workspace_bytes(int B, int N, int qsplit);
 
+/* The whole attention backward in ONE key-stationary sweep (S, dP and the exponentials are computed once per (query, key) pair
+ * instead of once in each of the two kernels above): dK / dV stay in registers, dQ is summed over the 256-key workgroups by fp32
+ * atomics into `workspace` (osuf_mqa_bwd_fused_workspace_bytes(B, H, N, qsplit) bytes, 16-byte aligned; zeroed by the call) and
+ * a finishing pass scales / un-rotates / casts it into dq.  dq / dk / dv, rope tables, qsplit: as above.  The dQ sum order is not
+ * fixed (atomics): results vary in the last fp32 bits between runs, as with autograd's own atomics in SDPA backward.
+ * replaces: the same call sites as osuf_mqa_bwd_dq + osuf_mqa_bwd_dkv (backward of attention.py:94-99 under unet.py:125-141). */
+int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
+                       const float* lse2, const float* delta, void* dq, long lddq, void* dk, void* dv, long lddk, int B, int H,
+                       int N, int head_dim, float scale, int out_dtype, const float* rope_cos, const float* rope_sin,
+                       float* workspace, long workspace_bytes, int qsplit, hipStream_t stream);
+long osuf_mqa_bwd_fused_workspace_bytes(int B, int H, int N, int qsplit);
+
 /* ---- layout / scheduler / optimizer (elementwise.hip) ----------------------------------------------------------
  * replaces: the (B,C,L) <-> (B,L,C) rearranges (modules/unet.py:180,183) at the model boundary, torch.cat (unet.py:500,
  *           507,510), DDIMScheduler.add_noise / .step (models/diffusion.py:96,75; diffusers 0.29.2), the CFG combine

@@ -831,6 +831,223 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_pipe_kernel(AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Fused backward: the key-stationary dK/dV sweep ALSO produces dQ, so S / dP / exp are computed once per (query, key) pair
+// (5 matrix products per tile instead of the 7 of the dQ + dK/dV kernel pair).  A wave owns 32 keys as above (S, dP with the key on
+// the lane: the P / dS accumulators are directly the B operands of the dV^T / dK^T products).  dQ sums over the KEY (lane) index,
+// which needs one transpose: every wave stores its dS rows as bf16 into a [256 keys][32 queries] LDS image (double-buffered: the
+// image written in iteration `it` is consumed in iteration it+1, behind the loop's one barrier), and in the next iteration the 8
+// waves each take one 16 (query) x 16 (d) tile of dQ[32][64] = dS[32][256] K[256][64] -- v_mfma_f32_16x16x32_bf16 over the 256 keys,
+// both operands read column-wise (ds_read_b64_tr_b16) from the dS image and from a resident K image of the workgroup's keys.
+// The 256-key partial dQ is added to an fp32 dQ buffer with global float atomics (4 x 64-byte row segments per wave-instruction):
+// 8 KiB per iteration per workgroup, i.e. B*H*N*64*4 bytes x N/256 per launch -- at the chip's ~1.3 TB/s atomic rate that is the
+// floor of this kernel (6.6 ms at B=32, N=4096), still below the 9.0 ms of the two-kernel path.  A finishing pass scales, applies
+// the RoPE transpose and casts (dq_finish_kernel).  Ragged shapes: padded query rows have Q = dO = 0 and lse = +inf (P = dS = 0),
+// padded keys have zero K rows in the image (they add nothing to dQ) and are not stored.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ds_img_off(int key, int qchunk) {     // 8-byte chunk (4 queries) of a 64-byte row, xor-swizzled
+  return key * 64 + ((qchunk ^ ((key ^ (key >> 3)) & 7)) << 3);
+}
+
+__global__ __launch_bounds__(512) void mqa_bwd_fused_kernel(AttnArgs a, float* dq32) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][Q 4K | dO 4K | lse 128 | delta 128] | K image 32K | [2] dS image 16K
+  constexpr int NW = 8, kStage = 4096 + 4096 + 256;
+  char* kimg = smem + 2 * kStage;
+  char* eimg = kimg + 32768;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int nkb = (a.N + 32 * NW - 1) / (32 * NW);
+  const int per_split = (int)gridDim.x / a.qsplit;
+  const int part = (int)blockIdx.x / per_split, bid = (int)blockIdx.x - part * per_split;
+  const int xcd = bid & 7, qid = bid >> 3;
+  const int b = (qid / nkb) * 8 + xcd;
+  const int kb = qid % nkb;
+  if (b >= a.B) return;
+  const int key = kb * (32 * NW) + wave * 32 + lr;
+  const bool kok = key < a.N;
+  const float c = a.scale * kLog2e;
+  const int nqb = (a.N + 31) >> 5;
+  const int qb_per = (nqb + a.qsplit - 1) / a.qsplit;
+  const int qb_begin = part * qb_per, qb_end = min(nqb, qb_begin + qb_per);
+  if (qb_begin >= qb_end) return;                                  // uniform per workgroup, before any barrier
+  const int niter = (qb_end - qb_begin) * a.H;
+
+  bf16x8 kf[4], vf[4];
+  {
+    const long m = (long)b * a.N + key;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 z = {0u, 0u, 0u, 0u}, z2 = {0u, 0u, 0u, 0u};
+      if (kok) { z = *reinterpret_cast<const u32x4*>(a.k + m * a.ldk + 16 * ks + 8 * lh); z2 = *reinterpret_cast<const u32x4*>(a.v + m * a.ldv + 16 * ks + 8 * lh); }
+      kf[ks] = __builtin_bit_cast(bf16x8, z);
+      vf[ks] = __builtin_bit_cast(bf16x8, z2);
+      *reinterpret_cast<u32x4*>(kimg + tile_off(wave * 32 + lr, (2 * ks + lh) * 16)) = z;     // resident K image (zero rows beyond N)
+    }
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+
+  // stage loader (512 threads, one 16-B chunk each): chunks 0..255 = Q tile, 256..511 = dO tile; threads 0..31 lse, 32..63 delta
+  const int lt = tid & 255, lrow = lt >> 3, lchunk = lt & 7;
+  const bf16_t* lsrc = tid < 256 ? a.q : a.dout;
+  const long lld = tid < 256 ? a.ldq : a.lddo;
+  const int lds_dst = (tid < 256 ? 0 : 4096) + tile_off(lrow, lchunk * 16);
+  u32x4 rt; float rs = 0.f;
+  int ih = 0, ipb = qb_begin;                                     // (head, query block) of the next stage to load
+  auto load_stage = [&]() {
+    const int qrow = ipb * 32 + lrow;
+    u32x4 z = {0u, 0u, 0u, 0u};
+    rt = z;
+    if (qrow < a.N) rt = *reinterpret_cast<const u32x4*>(lsrc + ((long)b * a.N + qrow) * lld + ih * D + lchunk * 8);
+    if (tid < 64) {
+      const int qr = ipb * 32 + (tid & 31);
+      const long sidx = ((long)b * a.H + ih) * a.N + qr;
+      if (tid < 32) rs = qr < a.N ? a.lse2[sidx] : INFINITY;
+      else rs = qr < a.N ? a.delta[sidx] : 0.f;
+    }
+    if (++ih == a.H) { ih = 0; ++ipb; }
+  };
+  auto store_stage = [&](int slot) {
+    char* base = smem + slot * kStage;
+    *reinterpret_cast<u32x4*>(base + lds_dst) = rt;
+    if (tid < 64) reinterpret_cast<float*>(base + 8192)[tid] = rs;
+  };
+
+  // dQ tile of this wave: queries qh*16 .. +15, head-dim columns dq4*16 .. +15 of the pair handled one iteration earlier
+  const int qh = wave & 1, dq4 = wave >> 1;
+  const int g4 = lane >> 4, ip = lane & 15, tq = ip >> 2, tp = ip & 3;
+  int koff[2];                                                    // per-lane transposed-read offsets into the K image (rows 8*g4 + tq, +4)
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) koff[hf] = tile_off(8 * g4 + 4 * hf + tq, (dq4 * 16 + 4 * tp) * 2);
+  auto dq_tile = [&](const char* eb, int ph, int ppb) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      // k-step ks covers keys 32*ks .. +31 (rows 32*ks + 8*g4 + {0..7} of both images).  tile_off swizzles by (row >> 1) & 7, which a
+      // +32-row step leaves alone, so the K offsets advance by 4096 B; ds_img_off uses (row ^ row >> 3) & 7 and is recomputed.
+      const int r0 = 32 * ks + 8 * g4 + tq;
+      const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(eb + ds_img_off(r0, qh * 4 + tp)));
+      const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(eb + ds_img_off(r0 + 4, qh * 4 + tp)));
+      const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(kimg + koff[0] + ks * 4096));
+      const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(kimg + koff[1] + ks * 4096));
+      const s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const s16x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+    }
+    // accumulator: column n = lane & 15 -> d, row m = 4 * (lane >> 4) + r -> query
+    const int qrow0 = ppb * 32 + qh * 16 + 4 * g4;
+    float* dst = dq32 + ((long)b * a.N + qrow0) * (a.H * D) + ph * D + dq4 * 16 + ip;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (qrow0 + r < a.N) atomic_add_f32(dst + (long)r * (a.H * D), acc[r]);
+  };
+
+  const LaneOffs lo(lane);
+  load_stage(); store_stage(0);
+  __syncthreads();
+  int ph = 0, ppb = qb_begin;                                      // (head, query block) of the previous iteration's pair
+  int ch = 0, cpb = qb_begin;                                      // ... of the current one
+  for (int it = 0; it < niter; ++it) {
+    const char* qs = smem + (it & 1) * kStage;
+    const char* dos = qs + 4096;
+    const float* ls = reinterpret_cast<const float*>(qs + 8192);
+    // dQ of the previous pair first: its atomics are then older than this iteration's global prefetch in the in-order vmcnt queue
+    if (it > 0) dq_tile(eimg + ((it - 1) & 1) * 16384, ph, ppb);
+    if (it + 1 < niter) load_stage();
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(qs, lo, ks, 0), kf[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(dos, lo, ks, 0), vf[ks], dp, 0, 0, 0);
+    }
+    f32x16 ds;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(ls + 8 * g + 4 * lh);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(ls + 32 + 8 * g + 4 * lh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        float p = fast_exp2(fmaf(s[r], c, -l4[e]));
+        s[r] = p;
+        ds[r] = p * (dp[r] - d4[e]);                // * scale folded into the finishing passes
+      }
+    }
+    // dS rows of this wave's keys -> the transposing image (queries 8g + 4lh .. +3 = one 8-byte chunk)
+    {
+      char* eb = eimg + (it & 1) * 16384;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w2;
+        w2[0] = pack_bf16x2(ds[4 * g], ds[4 * g + 1]);
+        w2[1] = pack_bf16x2(ds[4 * g + 2], ds[4 * g + 3]);
+        *reinterpret_cast<u32x2*>(eb + ds_img_off(wave * 32 + lr, 2 * g + lh)) = w2;
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 pf = acc_to_frag(s, s2);
+      const bf16x8 df = acc_to_frag(ds, s2);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(dos, lo, s2 * 16, dt), pf, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(qs, lo, s2 * 16, dt), df, dk[dt], 0, 0, 0);
+      }
+    }
+    if (it + 1 < niter) store_stage((it + 1) & 1);
+    __syncthreads();
+    ph = ch; ppb = cpb;
+    if (++ch == a.H) { ch = 0; ++cpb; }
+  }
+  dq_tile(eimg + ((niter - 1) & 1) * 16384, ph, ppb);
+  if (kok && a.qsplit > 1) {
+    const long prow = ((long)part * a.B + b) * a.N + key;
+    store_grad_row(a.wsk + prow * D, dk, 1.f, nullptr, nullptr, lh);
+    store_grad_row(a.wsv + prow * D, dv, 1.f, nullptr, nullptr, lh);
+  } else if (kok) {
+    store_grad(a.dk, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dk, a.scale, a.rcos, a.rsin, key, lh);
+    store_grad(a.dv, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dv, 1.f, nullptr, nullptr, key, lh);
+  }
+}
+
+// finishing pass of the fused backward's dQ: fp32 sums [M][H*64] -> scale, RoPE transpose (as store_grad_row), cast, into dq [M][lddq]
+template <typename TO>
+__global__ __launch_bounds__(256) void dq_finish_kernel(const float* __restrict__ dq32, TO* dq, long lddq, long M, int N, int H, float scale,
+                                                        const float* __restrict__ rcos, const float* __restrict__ rsin) {
+  // one thread: 4 columns d0..d0+3 (d0 < 32) of one head and their partners d0+32..; 8 threads per (row, head)
+  const long total = M * H * 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int sub = (int)(idx & 7);
+    const long rh = idx >> 3;
+    const long m = rh / H;
+    const int h = (int)(rh - m * H), n = (int)(m % N), d0 = sub * 4;
+    float y1[4], y2[4];
+    load4(dq32 + m * ((long)H * D) + h * D + d0, y1);
+    load4(dq32 + m * ((long)H * D) + h * D + 32 + d0, y2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { y1[e] *= scale; y2[e] *= scale; }
+    if (rcos) {
+      float cs[4], sn[4];
+      load4(rcos + (long)n * 32 + d0, cs);
+      load4(rsin + (long)n * 32 + d0, sn);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a1 = y1[e] * cs[e] + y2[e] * sn[e];
+        const float a2 = y2[e] * cs[e] - y1[e] * sn[e];
+        y1[e] = a1; y2[e] = a2;
+      }
+    }
+    store4(dq + m * lddq + h * D + d0, y1);
+    store4(dq + m * lddq + h * D + 32 + d0, y2);
+  }
+}
+
 // second half of the query-split dK/dV path: sum the parts (fixed order), scale, un-rotate (RoPE backward, as store_grad_row), cast
 template <typename TO>
 __global__ __launch_bounds__(256) void dkv_finish_kernel(const float* __restrict__ wsk, const float* __restrict__ wsv, int parts, TO* dk, TO* dv,
@@ -1068,6 +1285,48 @@ extern "C" int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk
   } else {
     hipLaunchKernelGGL(mqa_bwd_dkv_pipe_kernel, grid, dim3(512), 3 * (4096 + 4096 + 256), stream, a);
   }
+  return osuf_launch_status();
+}
+
+// ---- fused backward (one sweep: dQ by fp32 atomics into a workspace, dK / dV in registers) --------------------------------
+// workspace = fp32 dQ sums [B*N][H*64] followed, for query-split shapes, by the dK / dV partial sums of osuf_mqa_bwd_dkv
+extern "C" long osuf_mqa_bwd_fused_workspace_bytes(int B, int H, int N, int qsplit) {
+  if (B <= 0 || H <= 0 || N <= 0 || qsplit < 0 || qsplit > 16) return 0;
+  return (long)B * N * H * D * (long)sizeof(float) + osuf_mqa_bwd_dkv_workspace_bytes(B, N, qsplit);
+}
+
+extern "C" int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
+                                  const float* lse2, const float* delta, void* dq, long lddq, void* dk, void* dv, long lddk, int B, int H,
+                                  int N, int head_dim, float scale, int out_dtype, const float* rope_cos, const float* rope_sin,
+                                  float* workspace, long workspace_bytes, int qsplit, hipStream_t stream) {
+  AttnArgs a;
+  int rc = fill_bwd_args(a, q, ldq, k, ldk, v, ldv, dout, lddo, lse2, delta, B, H, N, head_dim, scale);
+  if (rc) return rc;
+  if (lddq % 8 || lddk % 8 || !al16(dq) || !al16(dk) || !al16(dv) || (out_dtype != OSUF_DT_F32 && out_dtype != OSUF_DT_BF16) ||
+      ((rope_cos == nullptr) != (rope_sin == nullptr)) || qsplit < 0 || qsplit > 16 || !workspace || !al16(workspace) ||
+      workspace_bytes < osuf_mqa_bwd_fused_workspace_bytes(B, H, N, qsplit))
+    return OSUF_EINVAL;
+  a.dk = dk; a.dv = dv; a.lddk = lddk; a.g_bf16 = out_dtype == OSUF_DT_BF16; a.rcos = rope_cos; a.rsin = rope_sin;
+  const long M = (long)B * N;
+  float* dq32 = workspace;
+  float* wsp = workspace + M * H * D;
+  a.qsplit = dkv_qsplit(B, N, qsplit);
+  if (a.qsplit > 1) { a.wsk = wsp; a.wsv = wsp + (long)a.qsplit * B * N * D; }
+  hipError_t e = hipMemsetAsync(dq32, 0, (size_t)M * H * D * sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  const int lds = 2 * (4096 + 4096 + 256) + 32768 + 2 * 16384;
+  static bool once = ((void)hipFuncSetAttribute((const void*)mqa_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+  (void)once;
+  const int b8 = (B + 7) / 8 * 8;
+  hipLaunchKernelGGL(mqa_bwd_fused_kernel, dim3(((N + 255) / 256) * b8 * a.qsplit), dim3(512), lds, stream, a, dq32);
+  if (a.qsplit > 1) {
+    const unsigned fb = (unsigned)((M * 32 + 255) / 256);
+    if (a.g_bf16) hipLaunchKernelGGL(dkv_finish_kernel<bf16_t>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (bf16_t*)dk, (bf16_t*)dv, lddk, M, N, scale, rope_cos, rope_sin);
+    else hipLaunchKernelGGL(dkv_finish_kernel<float>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (float*)dk, (float*)dv, lddk, M, N, scale, rope_cos, rope_sin);
+  }
+  const int qb = ew_grid(M * H * 8);
+  if (a.g_bf16) hipLaunchKernelGGL(dq_finish_kernel<bf16_t>, dim3(qb), dim3(256), 0, stream, dq32, (bf16_t*)dq, lddq, M, N, H, scale, rope_cos, rope_sin);
+  else hipLaunchKernelGGL(dq_finish_kernel<float>, dim3(qb), dim3(256), 0, stream, dq32, (float*)dq, lddq, M, N, H, scale, rope_cos, rope_sin);
   return osuf_launch_status();
 }
 

@@ -647,7 +647,7 @@ class AttentionFn(torch.autograd.Function):
         do16 = ops.cast_rows(do, torch.bfloat16)                                 # SDPA backward runs in bf16 (attention.py:101)
         # attention + rope
         cos, sin = rope_tables(N, D, scale_base, x.device)
-        dqkv = ops.mqa_bwd(qkv_r, o, do16, lse, B, N, H, D, scale, dt, cos, sin)  # RoPE transpose + cast ride the kernels' epilogues
+        dqkv = ops.mqa_bwd(qkv_r, o, do16, lse, B, N, H, D, scale, dt, cos, sin, variant=ops.ATTN_BWD_DEFAULT)  # RoPE transpose + cast ride the kernels' epilogues
         # to_q / to_kv
         dwq = conv_wgrad(dqkv[..., : H * D], xn, wq, "same") if need[3] else None
         dwkv = conv_wgrad(dqkv[..., H * D:], xn, wkv, "same") if need[4] else None

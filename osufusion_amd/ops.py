@@ -319,7 +319,8 @@ def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.
     return o, lse
 
 
-ATTN_AUTO, ATTN_PLAIN, ATTN_PIPE = 0, 1, 2
+ATTN_AUTO, ATTN_PLAIN, ATTN_PIPE, ATTN_FUSED = 0, 1, 2, 3
+ATTN_BWD_DEFAULT = ATTN_AUTO          # what AttentionFn.backward asks for: the dQ + dK/dV kernel pair (AUTO) or the fused sweep
 
 
 def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, D: int, scale: float,
@@ -334,6 +335,12 @@ def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Ten
     base, gbase, es = qkv.data_ptr(), dqkv.data_ptr(), dqkv.element_size()
     kp, vp, ldo_ = base + 2 * H * D, base + 2 * (H + 1) * D, _rows(do)[2]
     call("osuf_attn_delta", _p(do), ldo_, _p(o), _rows(o)[2], _DT[o.dtype], _p(delta), B, H, N, D, _stream())
+    if variant == ATTN_FUSED:
+        need = _lib.load().osuf_mqa_bwd_fused_workspace_bytes(B, H, N, qsplit)
+        ws = _workspace(need, qkv.device)
+        call("osuf_mqa_bwd_fused", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase, W, gbase + es * H * D,
+             gbase + es * (H + 1) * D, W, B, H, N, D, scale, _DT[out_dtype], _p(cos), _p(sin), _p(ws), need, qsplit, _stream(), meta=N)
+        return dqkv
     call("osuf_mqa_bwd_dq", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase, W, B, H, N, D, scale, _DT[out_dtype],
          _p(cos), _p(sin), variant, _stream(), meta=N)
     need = _lib.load().osuf_mqa_bwd_dkv_workspace_bytes(B, N, qsplit)  # > 0: short sequence (or forced), the query range is split

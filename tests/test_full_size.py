@@ -108,7 +108,10 @@ def test_full_size_one_sample_gradient_vs_oracle(full):
     try:
         trainer = Trainer(model, compute_dtype=torch.float32, reorder_buckets=False)
         names = {id(q): n for n, q in model.named_parameters()}
-        for mode, tol_loss, tol_flat, tol_norm_max, tol_norm_med in ((torch.float32, 1e-4, 5e-3, 3e-2, 1e-3),
+        # per-parameter errors are taken relative to max(|ref_i|, 1e-4 x the mean parameter-gradient norm): a handful of gradients
+        # are exactly zero in exact arithmetic (GlobalContext's to_k.bias: the softmax over L ignores a constant shift)
+        floor = 1e-4 * ref_flat.norm().item() / len(gref) ** 0.5
+        for mode, tol_loss, tol_flat, tol_norm_max, tol_norm_med in ((torch.float32, 1e-5, 2e-3, 2e-2, 1e-3),
                                                                      (torch.bfloat16, 2e-2, 6e-2, 2.5e-1, 3e-2)):
             trainer.flat.zero_grad()
             with oa.forced_compute_dtype(mode):
@@ -119,11 +122,11 @@ def test_full_size_one_sample_gradient_vs_oracle(full):
             got_flat = torch.cat([got[k].reshape(-1) for k in gref]).double()
             e_loss = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
             e_flat = ((got_flat - ref_flat).norm() / ref_flat.norm()).item()
-            rel_norm = torch.tensor([abs(got[k].double().norm().item() - gref[k].double().norm().item()) / (gref[k].double().norm().item() + 1e-30)
+            rel_norm = torch.tensor([(got[k].double() - gref[k].double()).norm().item() / max(gref[k].double().norm().item(), floor)
                                      for k in gref])
             tag = "fp32" if mode == torch.float32 else "bf16"
-            report(f"full_size_gradient_vs_oracle/{tag}", loss_rel=e_loss, flat_grad_rel_l2=e_flat, grad_norm_rel_max=rel_norm.max(),
-                   grad_norm_rel_median=rel_norm.median())
+            report(f"full_size_gradient_vs_oracle/{tag}", loss_rel=e_loss, flat_grad_rel_l2=e_flat, per_param_rel_l2_max=rel_norm.max(),
+                   per_param_rel_l2_median=rel_norm.median())
             assert e_loss < tol_loss, (tag, e_loss)
             assert e_flat < tol_flat, (tag, e_flat)
             assert rel_norm.max() < tol_norm_max and rel_norm.median() < tol_norm_med, (tag, rel_norm.max(), rel_norm.median())

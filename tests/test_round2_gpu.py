@@ -47,7 +47,7 @@ def test_every_attention_backward_kernel_vs_fp32_autograd(N):
     o, lse = ops.mqa_fwd(qkv, Bn, N, H, D, torch.bfloat16, D ** -0.5)
     assert rell2(o.float(), o_ref) < 5e-3                              # bf16 P and bf16 output rounding
     cases = [("auto", ops.ATTN_AUTO, 0), ("plain", ops.ATTN_PLAIN, 0), ("pipe-unsplit", ops.ATTN_PIPE, 1), ("pipe-split2", ops.ATTN_PIPE, 2),
-             ("pipe-split4", ops.ATTN_PIPE, 4)]
+             ("pipe-split4", ops.ATTN_PIPE, 4), ("fused", ops.ATTN_FUSED, 0), ("fused-split2", ops.ATTN_FUSED, 2)]
     outs = {}
     for name, variant, qsplit in cases:
         dqkv = ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5, variant=variant, qsplit=qsplit)
@@ -62,7 +62,7 @@ def test_every_attention_backward_kernel_vs_fp32_autograd(N):
     assert rell2(outs["plain"], outs["pipe-unsplit"]) < 2e-3
     # fused RoPE-transpose epilogue of the pipelined kernels == the stand-alone rope_bwd kernel on their fp32 result
     cos, sin = Fn.rope_tables(N, D, 2 * N, DEV)
-    for name, variant, qsplit in cases[2:4]:
+    for name, variant, qsplit in cases[2:4] + cases[5:]:
         ref_r = ops.rope_bwd(outs[name], torch.bfloat16, cos, sin, N, H + 1, H + 2, D)
         got_r = ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5, torch.bfloat16, cos, sin, variant=variant, qsplit=qsplit)
         assert relmax(got_r.float(), ref_r.float()) < 8e-3, name
@@ -124,7 +124,9 @@ def test_forward_with_cond_scale_vs_oracle(golden_dir):
                 got = model.unet.forward_with_cond_scale(x.to(DEV), a.to(DEV), t.to(DEV), c.to(DEV), cond_scale=s)
             e = rell2(got, want)
             report(f"forward_with_cond_scale/{s}", rel_l2=e)
-            assert e < 1e-3, (s, e)
+            # each branch sits at the reference's own bf16-attention noise floor (3.8e-4 on this net); guidance
+            # extrapolates: err(null + s (cond - null)) <= (s + |s - 1|) x the per-forward error relative to a similar norm
+            assert e < (1e-3 if s == 1.0 else 1e-3 * (2 * s - 1)), (s, e)
 
 
 @pytest.mark.parametrize("N", [96, 1000])
@@ -151,7 +153,7 @@ def test_set_full_bf16_switches_every_kernel_to_bf16(golden_dir):
     from osufusion_amd.pattern import synth_inputs
     meta, cfgd, model = _build_model("unet_tiny", golden_dir)
     x, a, c, t, noise = (torch.from_numpy(v).to(DEV) for v in synth_inputs("fullbf16", 2, 256))
-    with torch.no_grad():
+    with torch.no_grad(), ops.reproducible_mode(True):                # fixed-order reductions: two bf16 runs agree bit for bit
         with oa.forced_compute_dtype(torch.float32):
             y32 = model.unet(x, a, t, c)
         with oa.forced_compute_dtype(torch.bfloat16):
@@ -239,9 +241,11 @@ def test_trainer_gradient_accumulation_and_relayout(golden_dir):
         assert tr2.opt.step_count == 1 and abs(n1.item() - n2.item()) < 2e-3 * n1.item()
         assert [id(p) for p in tr2.flat.params] != first_layout, "the completion order differs from reverse registration order"
         g2, m2st = named(tr2, tr2.flat.grad), named(tr2, tr2.opt.exp_avg)
+        gfloor = 1e-5 * max(v.abs().max().item() for v in g1.values())      # some gradients are exactly zero in exact arithmetic
+        mfloor = 1e-5 * max(v.abs().max().item() for v in m1st.values())    # (GlobalContext's to_k.bias): compare above a floor
         for k in g1:
-            assert relmax(g2[k] / 2, g1[k]) < 2e-3 or g1[k].abs().max() < 1e-9, k     # sum of two half-batch means = 2 x full mean
-            assert relmax(m2st[k], m1st[k]) < 2e-3 or m1st[k].abs().max() < 1e-12, k   # Adam moments moved with their parameter
+            assert relmax(g2[k] / 2, g1[k]) < 2e-3 or g1[k].abs().max() < gfloor, k    # sum of two half-batch means = 2 x full mean
+            assert relmax(m2st[k], m1st[k]) < 2e-3 or m1st[k].abs().max() < mfloor, k  # Adam moments moved with their parameter
         for p, o in zip(tr2.flat.params, tr2.flat.offsets):
             assert p.data_ptr() == tr2.flat.data.data_ptr() + 4 * o and p.grad.data_ptr() == tr2.flat.grad.data_ptr() + 4 * o
         tr2.step(x[:2], a[:2], c[:2], noise[:2], t[:2])

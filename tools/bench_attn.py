@@ -13,7 +13,7 @@ def timeit(fn, iters=10):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
-print(f"{'N':>6s} {'fwd ms':>8s} {'TF/s':>6s} | {'dq ms':>8s} {'TF/s':>6s} | {'dkv ms':>8s} {'TF/s':>6s}")
+print(f"{'N':>6s} {'fwd ms':>8s} {'TF/s':>6s} | {'dq ms':>8s} {'TF/s':>6s} | {'dkv ms':>8s} {'TF/s':>6s} | {'fused ms':>8s} {'alg TF/s':>8s} (whole backward = 2 x fwd FLOPs)")
 for N in ([int(a) for a in sys.argv[1:]] or [4096, 2048, 1024, 512]):
     qkv = torch.randn(B, N, (H + 2) * D, device=dev).to(torch.bfloat16)
     o, lse = ops.mqa_fwd(qkv, B, N, H, D, torch.bfloat16, D ** -0.5)
@@ -31,4 +31,8 @@ for N in ([int(a) for a in sys.argv[1:]] or [4096, 2048, 1024, 512]):
     t1 = timeit(lambda: ops.mqa_fwd(qkv, B, N, H, D, torch.bfloat16, D ** -0.5))
     t2 = timeit(lambda: ops.call("osuf_mqa_bwd_dq", base, ld, kp, ld, vp, ld, do.data_ptr(), H * D, lse.data_ptr(), delta.data_ptr(), gbase, W, B, H, N, D, D ** -0.5, 0, None, None, 0, st))
     t3 = timeit(lambda: ops.call("osuf_mqa_bwd_dkv", base, ld, kp, ld, vp, ld, do.data_ptr(), H * D, lse.data_ptr(), delta.data_ptr(), gbase + 4 * H * D, gbase + 4 * (H + 1) * D, W, B, H, N, D, D ** -0.5, 0, None, None, wsp, need, 0, 0, st))
-    print(f"{N:6d} {t1:8.3f} {f / t1 / 1e9:6.0f} | {t2:8.3f} {1.5 * f / t2 / 1e9:6.0f} | {t3:8.3f} {2 * f / t3 / 1e9:6.0f}", flush=True)
+    cos = sin = None
+    t4 = timeit(lambda: ops.mqa_bwd(qkv, o, do, lse, B, N, H, D, D ** -0.5, torch.bfloat16, cos, sin, variant=ops.ATTN_FUSED))
+    t5 = timeit(lambda: ops.mqa_bwd(qkv, o, do, lse, B, N, H, D, D ** -0.5, torch.bfloat16, cos, sin, variant=ops.ATTN_AUTO))
+    print(f"{N:6d} {t1:8.3f} {f / t1 / 1e9:6.0f} | {t2:8.3f} {1.5 * f / t2 / 1e9:6.0f} | {t3:8.3f} {2 * f / t3 / 1e9:6.0f} | {t4:8.3f} {2 * f / t4 / 1e9:8.0f}"
+          f"  [ops.mqa_bwd incl. delta + finish: fused {t4:.3f} ms vs pair {t5:.3f} ms]", flush=True)
