@@ -126,7 +126,8 @@ def main() -> None:
                          "block{1,2}.proj (trainer_peft.py:236-244), base frozen; the reference runs R=32, config 5 says 16")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the extra fp32-compute-mode step (the mode in which the 1e-3 parity bound holds)")
-    ap.add_argument("--attn-bwd", choices=["auto", "pair", "fused"], default="auto", help="attention backward: the dQ + dK/dV kernel pair or the fused sweep")
+    ap.add_argument("--attn-bwd", choices=["auto", "pair", "fused", "slabs"], default="auto",
+                    help="attention backward: auto = the library default (fused sweep, atomic dQ); pair = dQ + dK/dV kernels; slabs = fused, fixed-order dQ")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,7 +157,7 @@ def main() -> None:
             for m in LL.lora_modules(model):
                 m.lora_B["default"].weight.normal_(0.0, 0.02)
     if args.attn_bwd != "auto":
-        ops.ATTN_BWD_DEFAULT = ops.ATTN_FUSED if args.attn_bwd == "fused" else ops.ATTN_AUTO
+        ops.ATTN_BWD_DEFAULT = {"fused": ops.ATTN_FUSED, "slabs": ops.ATTN_FUSED_SLABS, "pair": ops.ATTN_AUTO}[args.attn_bwd]
     trainer = Trainer(model, lr=1e-4, weight_decay=1e-2, clip_grad_norm=1.0, compute_dtype=torch.bfloat16)
     x, a, c, noise, t = synth_batch(rank, device, args.batch, args.length)
 

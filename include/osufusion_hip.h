@@ -30,6 +30,9 @@ extern "C" {
 #define OSUF_ATTN_AUTO 0
 #define OSUF_ATTN_PLAIN 1
 #define OSUF_ATTN_PIPE 2
+/* `dq_mode` of osuf_mqa_bwd_fused: fp32 atomics (default), or per-key-block slabs summed in a fixed order */
+#define OSUF_DQ_ATOMIC 0
+#define OSUF_DQ_SLABS 1
 
 int osuf_version(void);
 
@@ -133,16 +136,19 @@ int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk, const voi
 long osuf_mqa_bwd_dkv_workspace_bytes(int B, int N, int qsplit);
 
 /* The whole attention backward in ONE key-stationary sweep (S, dP and the exponentials are computed once per (query, key) pair
- * instead of once in each of the two kernels above): dK / dV stay in registers, dQ is summed over the 256-key workgroups by fp32
- * atomics into `workspace` (osuf_mqa_bwd_fused_workspace_bytes(B, H, N, qsplit) bytes, 16-byte aligned; zeroed by the call) and
- * a finishing pass scales / un-rotates / casts it into dq.  dq / dk / dv, rope tables, qsplit: as above.  The dQ sum order is not
- * fixed (atomics): results vary in the last fp32 bits between runs, as with autograd's own atomics in SDPA backward.
+ * instead of once in each of the two kernels above): dK / dV stay in registers; every 256-key workgroup leaves its partial dQ in
+ * `workspace` -- dq_mode OSUF_DQ_ATOMIC: fp32 atomics into one [B*N][H*64] buffer (sum order not fixed: the last fp32 bits vary
+ * between runs, as with autograd's own SDPA backward); OSUF_DQ_SLABS: one slab per key block in the output's element type, plain
+ * stores, added in key-block order by the finishing pass (bit-reproducible, slower) -- and a finishing pass scales / un-rotates /
+ * casts it into dq.  workspace:
+ * osuf_mqa_bwd_fused_workspace_bytes(B, H, N, out_dtype, qsplit, dq_mode) bytes, 16-byte aligned.  dq / dk / dv, rope tables,
+ * qsplit: as above.
  * replaces: the same call sites as osuf_mqa_bwd_dq + osuf_mqa_bwd_dkv (backward of attention.py:94-99 under unet.py:125-141). */
 int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
                        const float* lse2, const float* delta, void* dq, long lddq, void* dk, void* dv, long lddk, int B, int H,
                        int N, int head_dim, float scale, int out_dtype, const float* rope_cos, const float* rope_sin,
-                       float* workspace, long workspace_bytes, int qsplit, hipStream_t stream);
-long osuf_mqa_bwd_fused_workspace_bytes(int B, int H, int N, int qsplit);
+                       float* workspace, long workspace_bytes, int qsplit, int dq_mode, hipStream_t stream);
+long osuf_mqa_bwd_fused_workspace_bytes(int B, int H, int N, int out_dtype, int qsplit, int dq_mode);
 
 /* ---- layout / scheduler / optimizer (elementwise.hip) ----------------------------------------------------------
  * replaces: the (B,C,L) <-> (B,L,C) rearranges (modules/unet.py:180,183) at the model boundary, torch.cat (unet.py:500,
@@ -216,6 +222,13 @@ int osuf_log_vqt(const float* wave_pad, long n_pad, const float* bank, int K, in
                  float* spec_ws, float* out, long ldo, long frames, hipStream_t stream);
 int osuf_vqt_logmag(const float* spec, long ld, float* out, long ldo, const float* scale, int bins, long frames, float eps,
                     hipStream_t stream);
+
+/* The two helpers of librosa.vqt's octave recursion (core/constantq.py: after each octave, while the hop is even, the signal is
+ * resampled by 1/2 with res_type="soxr_hq", scale=True): osuf_fir_decimate2 -- out[m] = sum_j taps[j] * in[2m + j - (ntaps-1)/2],
+ * zeros outside the input, ntaps odd (the taps carry the sqrt(2)); osuf_frame_rows -- out[t][i] = in[t*hop + i] for the octaves
+ * whose hop (22, 11 samples) is not a multiple of 4 and cannot be read in place by osuf_log_vqt (call it with hop = K then). */
+int osuf_fir_decimate2(const float* in, long n_in, const float* taps, int ntaps, float* out, long n_out, hipStream_t stream);
+int osuf_frame_rows(const float* in, long n_in, int hop, int K, float* out, long frames, hipStream_t stream);
 
 /* Measurement aid (no reference counterpart): sustained shader clock under an MFMA (mode 1) or VALU (mode 0) load.
  * out[2*block] = shader cycles, out[2*block+1] = 100 MHz wall ticks. */

@@ -42,8 +42,8 @@ SIGNATURES = {
     "osuf_mqa_bwd_dq": [P, L, P, L, P, L, P, L, P, P, P, L, I, I, I, I, F, I, P, P, I, P],
     "osuf_mqa_bwd_dkv": [P, L, P, L, P, L, P, L, P, P, P, P, L, I, I, I, I, F, I, P, P, P, L, I, I, P],
     "osuf_mqa_bwd_dkv_workspace_bytes": [I, I, I],
-    "osuf_mqa_bwd_fused": [P, L, P, L, P, L, P, L, P, P, P, L, P, P, L, I, I, I, I, F, I, P, P, P, L, I, P],
-    "osuf_mqa_bwd_fused_workspace_bytes": [I, I, I, I],
+    "osuf_mqa_bwd_fused": [P, L, P, L, P, L, P, L, P, P, P, L, P, P, L, I, I, I, I, F, I, P, P, P, L, I, I, P],
+    "osuf_mqa_bwd_fused_workspace_bytes": [I, I, I, I, I, I],
     "osuf_ncl_to_rows": [I, P, P, L, I, I, I, I, I, P],
     "osuf_rows_to_ncl": [I, P, L, P, I, I, I, P],
     "osuf_copy2d": [I, P, L, I, P, L, I, I, P],
@@ -63,6 +63,8 @@ SIGNATURES = {
     "osuf_clock_probe": [I, I, I, P, P],
     "osuf_log_vqt": [P, L, P, I, I, I, P, F, P, P, L, L, P],
     "osuf_vqt_logmag": [P, L, P, L, P, I, L, F, P],
+    "osuf_fir_decimate2": [P, L, P, I, P, L, P],
+    "osuf_frame_rows": [P, L, I, I, P, L, P],
     "osuf_skinny_fwd": [I, P, L, P, P, P, L, I, I, I, I, I, P],
     "osuf_skinny_bwd": [I, P, L, P, L, P, L, P, P, L, P, P, I, I, I, I, I, I, P],
 }

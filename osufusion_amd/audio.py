@@ -7,10 +7,18 @@ definition -- lengths ``Q*sr/(f + gamma/alpha)`` with the ERB default ``gamma = 
 normalisation, ``sqrt(length)`` output scale -- and the transform itself is ONE strided-row fp32 MFMA GEMM over the zero-padded
 waveform plus a fused |.|/log/transpose kernel (``csrc/audio.hip``).
 
-librosa evaluates the same filters through an octave-recursive FFT approximation (soxr resampling between octaves, 1 % sparsified
-one-sided spectra); this module evaluates them directly at the full sample rate.  librosa is absent from the build image and the
-reference holds no spectrogram fixtures, so the front end is **parity unpinned** against the reference; it is
-checked against ``oracle/vqt_oracle.py`` (fp64, FFT-domain evaluation) and analytic known answers.
+``load_audio`` / ``log_vqt`` follow librosa 0.10.1's ACTUAL evaluation of these filters (``librosa_plan`` below; oracle:
+``oracle.vqt_oracle.vqt_recursive``): octave by octave from the top, each octave's wavelets built at the current sample rate, kept
+as one-sided spectra with the smallest 1 % of their L1 mass dropped (``util.sparsify_rows``) and applied to centred rectangular
+frames; between octaves, while the hop is even (176 -> 88 -> 44 -> 22 -> 11), the signal is low-passed and decimated by 2 with a
+sqrt(2) gain (``resample(orig_sr=2, target_sr=1, res_type="soxr_hq", scale=True)``).  A product of one-sided spectra is a
+correlation of the frame with the kernel g[n] = sum_{k <= n_fft/2} B[k] e^{-2 pi i k n / n_fft}; those kernels are built on the host
+(numpy fp64) and every octave group becomes one strided-row fp32 MFMA GEMM (``osuf_log_vqt``), after ``osuf_fir_decimate2``.
+soxr itself is not in this image: the half-band filter is a Kaiser-windowed sinc to soxr's published HQ recipe (passband to 0.913
+of the new Nyquist, ~125 dB) -- every octave's filters sit below 0.36 of its Nyquist, where any such filter is flat, so its exact
+taps move the result by ~1e-5 of the peak.  ``log_vqt_direct`` keeps round 1's full-rate direct form (the quantity the recursion
+approximates: differs by up to 2 % of the peak in the three lowest octaves).  librosa is absent from the build image and the
+reference holds no spectrogram fixtures, so the front end is **parity unpinned** against the reference.
 """
 from __future__ import annotations
 
@@ -87,8 +95,136 @@ def n_frames(n_samples: int, hop_length: int = HOP_LENGTH) -> int:
     return 1 + n_samples // hop_length
 
 
+class OctaveGroup(NamedTuple):
+    decimations: int        # halvings of the sample rate before this group
+    hop: int                # hop at that rate
+    n_fft: int              # frame length (= K of the GEMM)
+    bin0: int               # first output bin (row) of the group
+    bank: np.ndarray        # (2*nb, n_fft) float32: real rows then imaginary rows of the correlation kernels, 1/sqrt(length) folded in
+
+
+class LibrosaPlan(NamedTuple):
+    groups: tuple           # OctaveGroup, top octave first
+    taps: np.ndarray        # half-band decimation filter (float32, odd length, includes sqrt(2))
+
+
+def halfband_taps(passband: float = 0.913, stopband: float = 1.0, atten_db: float = 125.0) -> np.ndarray:
+    """Zero-phase decimate-by-2 low-pass to soxr's HQ recipe (edges as fractions of the new Nyquist): Kaiser-windowed sinc."""
+    width = (stopband - passband) * 0.25
+    n = int(math.ceil((atten_db - 8.0) / (2.285 * 2.0 * math.pi * width))) | 1
+    fc = 0.5 * (passband + stopband) * 0.25
+    m = np.arange(n) - (n - 1) / 2
+    h = 2.0 * fc * np.sinc(2.0 * fc * m) * np.kaiser(n, 0.1102 * (atten_db - 8.7))
+    return h / h.sum() * math.sqrt(2.0)
+
+
+def _sparsify_rows(x: np.ndarray, quantile: float) -> np.ndarray:
+    out = np.zeros_like(x)
+    mags = np.abs(x)
+    srt = np.sort(mags, axis=1)
+    cum = np.cumsum(srt / mags.sum(axis=1, keepdims=True), axis=1)
+    for i, j in enumerate(np.argmin(cum < quantile, axis=1)):
+        keep = mags[i] >= srt[i, j]
+        out[i, keep] = x[i, keep]
+    return out
+
+
+@functools.lru_cache(maxsize=4)
+def librosa_plan(sr: int = SR, hop: int = HOP_LENGTH, fmin: float = FMIN, n_bins: int = AUDIO_DIM, bins_per_octave: int = OCTAVE_BINS,
+                 sparsity: float = 0.01) -> LibrosaPlan:
+    """The octave recursion of librosa.vqt as GEMM operands: consecutive octaves that share (rate, hop, n_fft) form one group."""
+    freqs = fmin * 2.0 ** (np.arange(n_bins, dtype=np.float64) / bins_per_octave)
+    r2 = 2.0 ** (2.0 / bins_per_octave)
+    alpha = (r2 - 1.0) / (r2 + 1.0)
+    shift = 24.7 / 0.108
+
+    def lengths_at(f, rate):
+        return rate / (alpha * (f + shift))
+
+    n_oct = -(-n_bins // bins_per_octave)
+    nf = min(bins_per_octave, n_bins)
+    groups, dec, my_hop = [], 0, hop
+    for i in range(n_oct):
+        lo, hi = max(0, n_bins - nf * (i + 1)), n_bins - nf * i
+        my_sr = sr / 2.0 ** dec
+        f_oct = freqs[lo:hi]
+        lens = lengths_at(f_oct, my_sr)
+        n_fft = 1 << int(math.ceil(math.log2(lens.max())))
+        basis = np.zeros((hi - lo, n_fft), dtype=np.complex128)
+        for k, (flen, f) in enumerate(zip(lens, f_oct)):
+            idx = np.arange(math.floor(-flen / 2), math.floor(flen / 2), dtype=np.float64)
+            n = idx.size
+            sig = np.exp(1j * 2.0 * np.pi * f / my_sr * idx) * (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n))
+            sig /= np.abs(sig).sum()
+            lp = (n_fft - n) // 2
+            basis[k, lp:lp + n] = sig * (flen / n_fft)
+        fb = np.fft.fft(basis, axis=1)[:, : n_fft // 2 + 1]
+        if sparsity > 0:
+            fb = _sparsify_rows(fb, sparsity)
+        fb = fb * math.sqrt(sr / my_sr) / np.sqrt(lengths_at(f_oct, sr))[:, None]            # + the final V /= sqrt(lengths)
+        kk, nn = np.arange(n_fft // 2 + 1)[:, None], np.arange(n_fft)[None, :]
+        g = fb @ np.exp(-2j * np.pi * kk * nn / n_fft)                                        # (nb, n_fft) correlation kernels
+        last = groups[-1] if groups else None
+        if last is not None and (last["dec"], last["hop"], last["n_fft"]) == (dec, my_hop, n_fft):
+            last["g"] = np.concatenate([g, last["g"]], axis=0)                                # lower octave = lower bins: prepend
+            last["bin0"] = lo
+        else:
+            groups.append(dict(dec=dec, hop=my_hop, n_fft=n_fft, bin0=lo, g=g))
+        if my_hop % 2 == 0:
+            my_hop //= 2
+            dec += 1
+    out = tuple(OctaveGroup(d["dec"], d["hop"], d["n_fft"], d["bin0"],
+                            np.concatenate([d["g"].real, d["g"].imag], axis=0).astype(np.float32)) for d in groups)
+    return LibrosaPlan(out, halfband_taps().astype(np.float32))
+
+
+_DEVICE_PLANS = {}
+
+
+def _device_plan(device: torch.device):
+    key = str(device)
+    if key not in _DEVICE_PLANS:
+        plan = librosa_plan()
+        _DEVICE_PLANS[key] = ([(g, torch.from_numpy(g.bank).to(device), torch.ones(g.bank.shape[0] // 2, dtype=torch.float32, device=device))
+                               for g in plan.groups], torch.from_numpy(plan.taps).to(device))
+    return _DEVICE_PLANS[key]
+
+
 def log_vqt(wave: Union[np.ndarray, torch.Tensor], device: Union[str, torch.device] = "cuda") -> torch.Tensor:
-    """(n_samples,) mono waveform at SR -> (AUDIO_DIM, 1 + n_samples // HOP_LENGTH) fp32 log-VQT on `device` (GPU only)."""
+    """(n_samples,) mono waveform at SR -> (AUDIO_DIM, 1 + n_samples // HOP_LENGTH) fp32 log-VQT on `device` (GPU only), evaluated
+    as librosa.vqt evaluates it (octave recursion; see the module docstring)."""
+    y = torch.as_tensor(wave)
+    if y.dim() != 1:
+        raise ValueError(f"expected a mono waveform, got shape {tuple(y.shape)}")
+    if y.numel() == 0:
+        raise ValueError("Empty audio")
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("osufusion_amd.audio.log_vqt runs on the GPU only (no CPU fallback)")
+    groups, taps = _device_plan(device)
+    frames = n_frames(y.numel())                                   # the top octave has the fewest frames (__trim_stack)
+    out = torch.empty((AUDIO_DIM, frames), dtype=torch.float32, device=device)
+    sig = y.to(device=device, dtype=torch.float32).contiguous()
+    level = 0
+    for g, bank, ones in groups:
+        while level < g.decimations:                               # resample(orig_sr=2, target_sr=1, "soxr_hq", scale=True)
+            sig = ops.fir_decimate2(sig, taps)
+            level += 1
+        n, K = sig.numel(), g.n_fft
+        n_pad = (frames - 1) * g.hop + K                           # centred frames: n_fft/2 zeros in front, zeros behind
+        pad = torch.zeros(max(n_pad, K // 2 + n), dtype=torch.float32, device=device)
+        pad[K // 2:K // 2 + n] = sig
+        nb = bank.shape[0] // 2
+        rows = out[g.bin0:g.bin0 + nb]
+        if g.hop % 4 == 0:
+            ops.log_vqt(pad, bank, ones, g.hop, frames, LOG_EPS, out=rows)
+        else:                                                      # hop 22 / 11: frame explicitly, then a dense GEMM
+            ops.log_vqt(ops.frame_rows(pad, g.hop, K, frames).reshape(-1), bank, ones, K, frames, LOG_EPS, out=rows)
+    return out
+
+
+def log_vqt_direct(wave: Union[np.ndarray, torch.Tensor], device: Union[str, torch.device] = "cuda") -> torch.Tensor:
+    """The same wavelets evaluated directly at the full rate for every bin (one GEMM; the quantity librosa's recursion approximates)."""
     y = torch.as_tensor(wave)
     if y.dim() != 1:
         raise ValueError(f"expected a mono waveform, got shape {tuple(y.shape)}")

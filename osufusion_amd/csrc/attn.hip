@@ -849,6 +849,12 @@ __device__ __forceinline__ int ds_img_off(int key, int qchunk) {     // 8-byte c
   return key * 64 + ((qchunk ^ ((key ^ (key >> 3)) & 7)) << 3);
 }
 
+// DQ_MODE 0: dQ by fp32 atomics into dq32 [B*N][H*64] (measured 7.4 ms at B=32, N=4096: the atomic floor above); 1 / 2: every
+// workgroup stores the dQ^T tiles of its 256 keys as bf16 / fp32 rows of its own slab ws[key block][b][n (padded to 32)][H*64]
+// with plain 8 / 16-byte stores (5x the atomic byte rate, MI355X_MICROARCH "Global float atomics") and dq_reduce_kernel adds the
+// slabs in key-block order -- deterministic, and the sweep is compute-bound again.  bf16 slabs round each 256-key partial once
+// (relative 2^-9, the rounding the bf16 dq output gets anyway); fp32 slabs serve the fp32 compute mode.
+template <int DQ_MODE>
 __global__ __launch_bounds__(512) void mqa_bwd_fused_kernel(AttnArgs a, float* dq32) {
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][Q 4K | dO 4K | lse 128 | delta 128] | K image 32K | [2] dS image 16K
   constexpr int NW = 8, kStage = 4096 + 4096 + 256;
@@ -890,24 +896,29 @@ __global__ __launch_bounds__(512) void mqa_bwd_fused_kernel(AttnArgs a, float* d
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
 
-  // stage loader (512 threads, one 16-B chunk each): chunks 0..255 = Q tile, 256..511 = dO tile; threads 0..31 lse, 32..63 delta
+  // stage loader (512 threads, one 16-B chunk each): chunks 0..255 = Q tile, 256..511 = dO tile; threads 0..31 lse, 32..63 delta.
+  // BRANCH-FREE on purpose: the kernel keeps float atomics in flight (they stay in the in-order vmcnt queue for ~3,000 cycles when
+  // every CU issues them), and hipcc's wait-count pass falls back to vmcnt(0) -- i.e. a full atomic round trip per iteration --
+  // as soon as a load or an atomic sits under an exec-masked or scalar branch.  So every lane always loads (row indices clamped,
+  // the value zeroed by a select afterwards) and loads are issued BEFORE the atomics of the same iteration: waiting for them is
+  // then a counted vmcnt(4) that leaves the four younger atomics in flight.
   const int lt = tid & 255, lrow = lt >> 3, lchunk = lt & 7;
   const bf16_t* lsrc = tid < 256 ? a.q : a.dout;
   const long lld = tid < 256 ? a.ldq : a.lddo;
   const int lds_dst = (tid < 256 ? 0 : 4096) + tile_off(lrow, lchunk * 16);
+  const float* ssrc = (tid & 32) ? a.delta : a.lse2;              // lanes 0-31 of each wave: lse, 32-63: delta (only wave 0 stores them)
+  const float sfill = (tid & 32) ? 0.f : INFINITY;
+  const int last_pb = qb_end - 1;
   u32x4 rt; float rs = 0.f;
   int ih = 0, ipb = qb_begin;                                     // (head, query block) of the next stage to load
   auto load_stage = [&]() {
-    const int qrow = ipb * 32 + lrow;
-    u32x4 z = {0u, 0u, 0u, 0u};
-    rt = z;
-    if (qrow < a.N) rt = *reinterpret_cast<const u32x4*>(lsrc + ((long)b * a.N + qrow) * lld + ih * D + lchunk * 8);
-    if (tid < 64) {
-      const int qr = ipb * 32 + (tid & 31);
-      const long sidx = ((long)b * a.H + ih) * a.N + qr;
-      if (tid < 32) rs = qr < a.N ? a.lse2[sidx] : INFINITY;
-      else rs = qr < a.N ? a.delta[sidx] : 0.f;
-    }
+    const int pbc = min(ipb, last_pb);                             // past the end: reload the last block (never consumed)
+    const int qrow = pbc * 32 + lrow, qr = pbc * 32 + (tid & 31);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(lsrc + ((long)b * a.N + min(qrow, a.N - 1)) * lld + ih * D + lchunk * 8);
+    const float sv = ssrc[((long)b * a.H + ih) * a.N + min(qr, a.N - 1)];
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    rt = qrow < a.N ? v : z;
+    rs = qr < a.N ? sv : sfill;
     if (++ih == a.H) { ih = 0; ++ipb; }
   };
   auto store_stage = [&](int slot) {
@@ -919,45 +930,66 @@ __global__ __launch_bounds__(512) void mqa_bwd_fused_kernel(AttnArgs a, float* d
   // dQ tile of this wave: queries qh*16 .. +15, head-dim columns dq4*16 .. +15 of the pair handled one iteration earlier
   const int qh = wave & 1, dq4 = wave >> 1;
   const int g4 = lane >> 4, ip = lane & 15, tq = ip >> 2, tp = ip & 3;
-  int koff[2];                                                    // per-lane transposed-read offsets into the K image (rows 8*g4 + tq, +4)
-#pragma unroll
-  for (int hf = 0; hf < 2; ++hf) koff[hf] = tile_off(8 * g4 + 4 * hf + tq, (dq4 * 16 + 4 * tp) * 2);
+  // The K-side operand of this wave's dQ tile (K[256 keys][16 d-columns], read column-wise) never changes during the sweep: its
+  // eight k-step fragments are read from the K image once, after the prologue barrier, and stay in registers (32 VGPRs; re-reading
+  // them every iteration was half of the dQ phase's LDS traffic, 8 KiB per wave and iteration).
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 kcol[8];
   auto dq_tile = [&](const char* eb, int ph, int ppb) {
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      // k-step ks covers keys 32*ks .. +31 (rows 32*ks + 8*g4 + {0..7} of both images).  tile_off swizzles by (row >> 1) & 7, which a
-      // +32-row step leaves alone, so the K offsets advance by 4096 B; ds_img_off uses (row ^ row >> 3) & 7 and is recomputed.
+      // k-step ks covers keys 32*ks .. +31: rows 32*ks + 8*g4 + {0..7} of the dS image, whose swizzle (row ^ row >> 3) & 7 changes with
+      // ks (+32 rows flips bit 2 of row >> 3), so the offsets are formed per k-step
       const int r0 = 32 * ks + 8 * g4 + tq;
       const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(eb + ds_img_off(r0, qh * 4 + tp)));
       const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(eb + ds_img_off(r0 + 4, qh * 4 + tp)));
-      const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(kimg + koff[0] + ks * 4096));
-      const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(kimg + koff[1] + ks * 4096));
       const s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-      const s16x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+      const s16x8 bv = kcol[ks];
+      // atomics: dQ tile (row = query); slabs: dQ^T tile (row = d), so that a lane ends up with 4 consecutive d of one query row
+      if constexpr (DQ_MODE == 0) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, av), acc, 0, 0, 0);
+    }
+    if constexpr (DQ_MODE != 0) {
+      // accumulator: column n = lane & 15 -> query, row m = 4 * (lane >> 4) + r -> d.  Slab rows are padded to whole 32-query
+      // blocks, so no store is masked (a branch around it would cost the counted waits, see the stage loader)
+      const long npad = (long)nqb * 32;
+      const long row = ((long)kb * a.B + b) * npad + ppb * 32 + qh * 16 + ip;
+      const float v4[4] = {acc[0], acc[1], acc[2], acc[3]};
+      if constexpr (DQ_MODE == 1) store4(reinterpret_cast<bf16_t*>(dq32) + row * (a.H * D) + ph * D + dq4 * 16 + 4 * g4, v4);
+      else store4(dq32 + row * (a.H * D) + ph * D + dq4 * 16 + 4 * g4, v4);
+      return;
     }
     // accumulator: column n = lane & 15 -> d, row m = 4 * (lane >> 4) + r -> query
+    // (no branch around the atomics, see the stage loader: a padded query row adds 0.0 to the sample's last row instead)
     const int qrow0 = ppb * 32 + qh * 16 + 4 * g4;
-    float* dst = dq32 + ((long)b * a.N + qrow0) * (a.H * D) + ph * D + dq4 * 16 + ip;
+    float* dst = dq32 + (long)b * a.N * (a.H * D) + ph * D + dq4 * 16 + ip;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (qrow0 + r < a.N) atomic_add_f32(dst + (long)r * (a.H * D), acc[r]);
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = qrow0 + r < a.N;
+      atomic_add_f32(dst + (long)min(qrow0 + r, a.N - 1) * (a.H * D), ok ? acc[r] : 0.f);
+    }
   };
 
   const LaneOffs lo(lane);
+  for (int i = tid; i < 16384 / 16; i += NW * 64) reinterpret_cast<u32x4*>(eimg + 16384)[i] = u32x4{0u, 0u, 0u, 0u};
   load_stage(); store_stage(0);
   __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {                                 // tile_off swizzles by (row >> 1) & 7: a +32-row step leaves it alone
+    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(kimg + tile_off(8 * g4 + tq, (dq4 * 16 + 4 * tp) * 2) + ks * 4096));
+    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(kimg + tile_off(8 * g4 + 4 + tq, (dq4 * 16 + 4 * tp) * 2) + ks * 4096));
+    kcol[ks] = s16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+  }
   int ph = 0, ppb = qb_begin;                                      // (head, query block) of the previous iteration's pair
   int ch = 0, cpb = qb_begin;                                      // ... of the current one
   for (int it = 0; it < niter; ++it) {
     const char* qs = smem + (it & 1) * kStage;
     const char* dos = qs + 4096;
     const float* ls = reinterpret_cast<const float*>(qs + 8192);
-    // dQ of the previous pair first: its atomics are then older than this iteration's global prefetch in the in-order vmcnt queue
-    if (it > 0) dq_tile(eimg + ((it - 1) & 1) * 16384, ph, ppb);
-    if (it + 1 < niter) load_stage();
+    // global prefetch of the next pair FIRST, then the previous pair's dQ (its four atomics are younger than the loads)
+    load_stage();
+    dq_tile(eimg + ((it + 1) & 1) * 16384, ph, ppb);               // it = 0: the zeroed image -> adds 0.0
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -1000,7 +1032,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_fused_kernel(AttnArgs a, float* d
         dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(qs, lo, s2 * 16, dt), df, dk[dt], 0, 0, 0);
       }
     }
-    if (it + 1 < niter) store_stage((it + 1) & 1);
+    store_stage((it + 1) & 1);                                     // (after the last pair: a stage nobody reads)
     __syncthreads();
     ph = ch; ppb = cpb;
     if (++ch == a.H) { ch = 0; ++cpb; }
@@ -1030,6 +1062,46 @@ __global__ __launch_bounds__(256) void dq_finish_kernel(const float* __restrict_
     float y1[4], y2[4];
     load4(dq32 + m * ((long)H * D) + h * D + d0, y1);
     load4(dq32 + m * ((long)H * D) + h * D + 32 + d0, y2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { y1[e] *= scale; y2[e] *= scale; }
+    if (rcos) {
+      float cs[4], sn[4];
+      load4(rcos + (long)n * 32 + d0, cs);
+      load4(rsin + (long)n * 32 + d0, sn);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a1 = y1[e] * cs[e] + y2[e] * sn[e];
+        const float a2 = y2[e] * cs[e] - y1[e] * sn[e];
+        y1[e] = a1; y2[e] = a2;
+      }
+    }
+    store4(dq + m * lddq + h * D + d0, y1);
+    store4(dq + m * lddq + h * D + 32 + d0, y2);
+  }
+}
+
+// dQ of the fused backward from the key-block slabs: sum the nkb slabs in key-block order (fixed: bit-reproducible), scale, RoPE
+// transpose (as store_grad_row), cast.  ws: [nkb][B][npad][H*64] TP; dq: [B*N][lddq] TO.
+template <typename TP, typename TO>
+__global__ __launch_bounds__(256) void dq_reduce_kernel(const TP* __restrict__ ws, int nkb, TO* dq, long lddq, int B, int N, int npad, int H,
+                                                        float scale, const float* __restrict__ rcos, const float* __restrict__ rsin) {
+  const long total = (long)B * N * H * 8;                          // one thread: d0..d0+3 (d0 < 32) of one head and the partners d0+32..
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int sub = (int)(idx & 7);
+    const long rh = idx >> 3;
+    const long m = rh / H;
+    const int h = (int)(rh - m * H), d0 = sub * 4;
+    const int bb = (int)(m / N), n = (int)(m - (long)bb * N);
+    const long slab = (long)B * npad * (H * D);
+    const TP* src = ws + ((long)bb * npad + n) * (H * D) + h * D + d0;
+    float y1[4] = {0.f, 0.f, 0.f, 0.f}, y2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < nkb; ++p) {
+      float u1[4], u2[4];
+      load4(src + p * slab, u1);
+      load4(src + p * slab + 32, u2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { y1[e] += u1[e]; y2[e] += u2[e]; }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) { y1[e] *= scale; y2[e] *= scale; }
     if (rcos) {
@@ -1288,45 +1360,69 @@ extern "C" int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk
   return osuf_launch_status();
 }
 
-// ---- fused backward (one sweep: dQ by fp32 atomics into a workspace, dK / dV in registers) --------------------------------
-// workspace = fp32 dQ sums [B*N][H*64] followed, for query-split shapes, by the dK / dV partial sums of osuf_mqa_bwd_dkv
-extern "C" long osuf_mqa_bwd_fused_workspace_bytes(int B, int H, int N, int qsplit) {
-  if (B <= 0 || H <= 0 || N <= 0 || qsplit < 0 || qsplit > 16) return 0;
-  return (long)B * N * H * D * (long)sizeof(float) + osuf_mqa_bwd_dkv_workspace_bytes(B, N, qsplit);
+// ---- fused backward (one sweep; dQ through key-block slabs or fp32 atomics, dK / dV in registers) ------------------------
+// dq_mode: OSUF_DQ_ATOMIC (default: fp32 atomics -- the faster one as measured, 7.8 vs 10.1 ms per backward at B=32, N=4096: the slab
+// stores are 32-byte pieces of 128-byte lines) or OSUF_DQ_SLABS (slabs in the output's element type, summed in a fixed order)
+// workspace = the dQ slabs / sums, followed, for query-split shapes, by the dK / dV partial sums of osuf_mqa_bwd_dkv
+static long fused_dq_bytes(int B, int H, int N, int out_dtype, int dq_mode) {
+  if (dq_mode == OSUF_DQ_ATOMIC) return (long)B * N * H * D * (long)sizeof(float);
+  const long npad = ((long)N + 31) / 32 * 32, nkb = ((long)N + 255) / 256;
+  return ((nkb * B * npad * H * D * (out_dtype == OSUF_DT_BF16 ? 2 : 4)) + 15) / 16 * 16;
+}
+extern "C" long osuf_mqa_bwd_fused_workspace_bytes(int B, int H, int N, int out_dtype, int qsplit, int dq_mode) {
+  if (B <= 0 || H <= 0 || N <= 0 || qsplit < 0 || qsplit > 16 || (dq_mode != OSUF_DQ_SLABS && dq_mode != OSUF_DQ_ATOMIC)) return 0;
+  return fused_dq_bytes(B, H, N, out_dtype, dq_mode) + osuf_mqa_bwd_dkv_workspace_bytes(B, N, qsplit);
 }
 
 extern "C" int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
                                   const float* lse2, const float* delta, void* dq, long lddq, void* dk, void* dv, long lddk, int B, int H,
                                   int N, int head_dim, float scale, int out_dtype, const float* rope_cos, const float* rope_sin,
-                                  float* workspace, long workspace_bytes, int qsplit, hipStream_t stream) {
+                                  float* workspace, long workspace_bytes, int qsplit, int dq_mode, hipStream_t stream) {
   AttnArgs a;
   int rc = fill_bwd_args(a, q, ldq, k, ldk, v, ldv, dout, lddo, lse2, delta, B, H, N, head_dim, scale);
   if (rc) return rc;
   if (lddq % 8 || lddk % 8 || !al16(dq) || !al16(dk) || !al16(dv) || (out_dtype != OSUF_DT_F32 && out_dtype != OSUF_DT_BF16) ||
       ((rope_cos == nullptr) != (rope_sin == nullptr)) || qsplit < 0 || qsplit > 16 || !workspace || !al16(workspace) ||
-      workspace_bytes < osuf_mqa_bwd_fused_workspace_bytes(B, H, N, qsplit))
+      (dq_mode != OSUF_DQ_SLABS && dq_mode != OSUF_DQ_ATOMIC) || workspace_bytes < osuf_mqa_bwd_fused_workspace_bytes(B, H, N, out_dtype, qsplit, dq_mode))
     return OSUF_EINVAL;
   a.dk = dk; a.dv = dv; a.lddk = lddk; a.g_bf16 = out_dtype == OSUF_DT_BF16; a.rcos = rope_cos; a.rsin = rope_sin;
   const long M = (long)B * N;
+  const long dq_bytes = fused_dq_bytes(B, H, N, out_dtype, dq_mode);
   float* dq32 = workspace;
-  float* wsp = workspace + M * H * D;
+  float* wsp = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + dq_bytes);
   a.qsplit = dkv_qsplit(B, N, qsplit);
   if (a.qsplit > 1) { a.wsk = wsp; a.wsv = wsp + (long)a.qsplit * B * N * D; }
-  hipError_t e = hipMemsetAsync(dq32, 0, (size_t)M * H * D * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
   const int lds = 2 * (4096 + 4096 + 256) + 32768 + 2 * 16384;
-  static bool once = ((void)hipFuncSetAttribute((const void*)mqa_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
+  static bool once = ((void)hipFuncSetAttribute((const void*)mqa_bwd_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+                      (void)hipFuncSetAttribute((const void*)mqa_bwd_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+                      (void)hipFuncSetAttribute((const void*)mqa_bwd_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
   (void)once;
   const int b8 = (B + 7) / 8 * 8;
-  hipLaunchKernelGGL(mqa_bwd_fused_kernel, dim3(((N + 255) / 256) * b8 * a.qsplit), dim3(512), lds, stream, a, dq32);
+  const dim3 grid(((N + 255) / 256) * b8 * a.qsplit);
+  if (dq_mode == OSUF_DQ_ATOMIC) {
+    hipError_t e = hipMemsetAsync(dq32, 0, (size_t)dq_bytes, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(mqa_bwd_fused_kernel<0>, grid, dim3(512), lds, stream, a, dq32);
+  } else if (a.g_bf16) {
+    hipLaunchKernelGGL(mqa_bwd_fused_kernel<1>, grid, dim3(512), lds, stream, a, dq32);
+  } else {
+    hipLaunchKernelGGL(mqa_bwd_fused_kernel<2>, grid, dim3(512), lds, stream, a, dq32);
+  }
   if (a.qsplit > 1) {
     const unsigned fb = (unsigned)((M * 32 + 255) / 256);
     if (a.g_bf16) hipLaunchKernelGGL(dkv_finish_kernel<bf16_t>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (bf16_t*)dk, (bf16_t*)dv, lddk, M, N, scale, rope_cos, rope_sin);
     else hipLaunchKernelGGL(dkv_finish_kernel<float>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (float*)dk, (float*)dv, lddk, M, N, scale, rope_cos, rope_sin);
   }
   const int qb = ew_grid(M * H * 8);
-  if (a.g_bf16) hipLaunchKernelGGL(dq_finish_kernel<bf16_t>, dim3(qb), dim3(256), 0, stream, dq32, (bf16_t*)dq, lddq, M, N, H, scale, rope_cos, rope_sin);
-  else hipLaunchKernelGGL(dq_finish_kernel<float>, dim3(qb), dim3(256), 0, stream, dq32, (float*)dq, lddq, M, N, H, scale, rope_cos, rope_sin);
+  const int nkb = (N + 255) / 256, npad = (N + 31) / 32 * 32;
+  if (dq_mode == OSUF_DQ_ATOMIC) {
+    if (a.g_bf16) hipLaunchKernelGGL(dq_finish_kernel<bf16_t>, dim3(qb), dim3(256), 0, stream, dq32, (bf16_t*)dq, lddq, M, N, H, scale, rope_cos, rope_sin);
+    else hipLaunchKernelGGL(dq_finish_kernel<float>, dim3(qb), dim3(256), 0, stream, dq32, (float*)dq, lddq, M, N, H, scale, rope_cos, rope_sin);
+  } else if (a.g_bf16) {
+    hipLaunchKernelGGL((dq_reduce_kernel<bf16_t, bf16_t>), dim3(qb), dim3(256), 0, stream, (const bf16_t*)dq32, nkb, (bf16_t*)dq, lddq, B, N, npad, H, scale, rope_cos, rope_sin);
+  } else {
+    hipLaunchKernelGGL((dq_reduce_kernel<float, float>), dim3(qb), dim3(256), 0, stream, (const float*)dq32, nkb, (float*)dq, lddq, B, N, npad, H, scale, rope_cos, rope_sin);
+  }
   return osuf_launch_status();
 }
 

@@ -43,7 +43,52 @@ __global__ __launch_bounds__(256) void vqt_logmag_kernel(const float* __restrict
   }
 }
 
+// Octave recursion of librosa.vqt (core/constantq.py): between octaves the signal is low-passed and decimated by 2
+//   out[m] = sum_j taps[j] * in[2m + j - (ntaps-1)/2]     (zeros outside [0, n_in); taps hold the sqrt(2) of resample(scale=True))
+// One output per thread, taps staged in LDS; a 4-minute song is 5.3 M samples x ~375 taps at the first stage: ~2 GFLOP, HBM-trivial.
+__global__ __launch_bounds__(256) void fir_decimate2_kernel(const float* __restrict__ in, long n_in, const float* __restrict__ taps, int ntaps,
+                                                            float* __restrict__ out, long n_out) {
+  extern __shared__ float st[];
+  for (int j = threadIdx.x; j < ntaps; j += blockDim.x) st[j] = taps[j];
+  __syncthreads();
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_out) return;
+  const long base = 2 * m - (ntaps - 1) / 2;
+  float acc = 0.f;
+  for (int j = 0; j < ntaps; ++j) {
+    const long i = base + j;
+    if (i >= 0 && i < n_in) acc = fmaf(st[j], in[i], acc);
+  }
+  out[m] = acc;
+}
+
+// rows[t][i] = in[t*hop + i] (0 beyond n_in): explicit framing for the low octaves, whose hops (22, 11 samples) are not 16-byte
+// multiples and so cannot be read in place by the GEMM loader
+__global__ __launch_bounds__(256) void frame_rows_kernel(const float* __restrict__ in, long n_in, int hop, int K, float* __restrict__ out,
+                                                         long frames) {
+  const long total = frames * K;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long t = e / K;
+    const long i = t * hop + (e - t * K);
+    out[e] = i < n_in ? in[i] : 0.f;
+  }
+}
+
 }  // namespace
+
+extern "C" int osuf_fir_decimate2(const float* in, long n_in, const float* taps, int ntaps, float* out, long n_out, hipStream_t stream) {
+  if (!in || !taps || !out || n_in <= 0 || n_out <= 0 || ntaps <= 0 || ntaps > 8192 || (ntaps & 1) == 0) return OSUF_EINVAL;
+  fir_decimate2_kernel<<<(unsigned)((n_out + 255) / 256), 256, ntaps * sizeof(float), stream>>>(in, n_in, taps, ntaps, out, n_out);
+  return osuf_launch_status();
+}
+
+extern "C" int osuf_frame_rows(const float* in, long n_in, int hop, int K, float* out, long frames, hipStream_t stream) {
+  if (!in || !out || n_in <= 0 || hop <= 0 || K <= 0 || frames <= 0) return OSUF_EINVAL;
+  long blocks = (frames * K + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  frame_rows_kernel<<<(unsigned)blocks, 256, 0, stream>>>(in, n_in, hop, K, out, frames);
+  return osuf_launch_status();
+}
 
 extern "C" int osuf_vqt_logmag(const float* spec, long ld, float* out, long ldo, const float* scale, int bins, long frames,
                                float eps, hipStream_t stream) {

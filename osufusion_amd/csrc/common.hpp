@@ -9,6 +9,9 @@
 #define OSUF_ATTN_AUTO 0
 #define OSUF_ATTN_PLAIN 1
 #define OSUF_ATTN_PIPE 2
+// how the fused attention backward sums dQ over its 256-key workgroups
+#define OSUF_DQ_ATOMIC 0
+#define OSUF_DQ_SLABS 1
 
 typedef uint16_t bf16_t;                                   // raw bf16 bits in HBM
 typedef __attribute__((ext_vector_type(4))) float f32x4;

@@ -319,8 +319,10 @@ def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.
     return o, lse
 
 
-ATTN_AUTO, ATTN_PLAIN, ATTN_PIPE, ATTN_FUSED = 0, 1, 2, 3
-ATTN_BWD_DEFAULT = ATTN_AUTO          # what AttentionFn.backward asks for: the dQ + dK/dV kernel pair (AUTO) or the fused sweep
+ATTN_AUTO, ATTN_PLAIN, ATTN_PIPE, ATTN_FUSED, ATTN_FUSED_SLABS = 0, 1, 2, 3, 4
+# What AttentionFn.backward asks for: ATTN_FUSED = one key-stationary sweep, dQ by fp32 atomics (fastest at every UNet shape, measured
+# round 2); ATTN_FUSED_SLABS = the same sweep with a fixed-order dQ sum (bit-reproducible); ATTN_AUTO = the dQ + dK/dV kernel pair.
+ATTN_BWD_DEFAULT = ATTN_FUSED
 
 
 def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, D: int, scale: float,
@@ -335,11 +337,12 @@ def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Ten
     base, gbase, es = qkv.data_ptr(), dqkv.data_ptr(), dqkv.element_size()
     kp, vp, ldo_ = base + 2 * H * D, base + 2 * (H + 1) * D, _rows(do)[2]
     call("osuf_attn_delta", _p(do), ldo_, _p(o), _rows(o)[2], _DT[o.dtype], _p(delta), B, H, N, D, _stream())
-    if variant == ATTN_FUSED:
-        need = _lib.load().osuf_mqa_bwd_fused_workspace_bytes(B, H, N, qsplit)
+    if variant in (ATTN_FUSED, ATTN_FUSED_SLABS):
+        mode = 1 if variant == ATTN_FUSED_SLABS else 0
+        need = _lib.load().osuf_mqa_bwd_fused_workspace_bytes(B, H, N, _DT[out_dtype], qsplit, mode)
         ws = _workspace(need, qkv.device)
         call("osuf_mqa_bwd_fused", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase, W, gbase + es * H * D,
-             gbase + es * (H + 1) * D, W, B, H, N, D, scale, _DT[out_dtype], _p(cos), _p(sin), _p(ws), need, qsplit, _stream(), meta=N)
+             gbase + es * (H + 1) * D, W, B, H, N, D, scale, _DT[out_dtype], _p(cos), _p(sin), _p(ws), need, qsplit, mode, _stream(), meta=N)
         return dqkv
     call("osuf_mqa_bwd_dq", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase, W, B, H, N, D, scale, _DT[out_dtype],
          _p(cos), _p(sin), variant, _stream(), meta=N)
@@ -542,14 +545,35 @@ def cast_f32_bf16(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     return dst
 
 
-def log_vqt(wave_pad: torch.Tensor, bank: torch.Tensor, scale: torch.Tensor, hop: int, frames: int, eps: float = 1e-10) -> torch.Tensor:
-    """out[k][t] = log(scale[k] |sum_n wave_pad[t*hop+n] (bank[k][n] + i bank[bins+k][n])| + eps) -> (bins, frames) fp32 (audio.hip)."""
+def fir_decimate2(sig: torch.Tensor, taps: torch.Tensor) -> torch.Tensor:
+    """out[m] = sum_j taps[j] sig[2m + j - (len(taps)-1)/2], m < ceil(len(sig)/2) (zero extension)."""
+    assert sig.is_cuda and sig.dtype == torch.float32 and sig.dim() == 1 and sig.is_contiguous() and taps.dtype == torch.float32
+    n_out = (sig.numel() + 1) // 2
+    out = torch.empty(n_out, dtype=torch.float32, device=sig.device)
+    call("osuf_fir_decimate2", _p(sig), sig.numel(), _p(taps), taps.numel(), _p(out), n_out, _stream())
+    return out
+
+
+def frame_rows(sig: torch.Tensor, hop: int, K: int, frames: int) -> torch.Tensor:
+    """(frames, K) rows sig[t*hop : t*hop + K] (zeros past the end)."""
+    assert sig.is_cuda and sig.dtype == torch.float32 and sig.dim() == 1 and sig.is_contiguous()
+    out = torch.empty((frames, K), dtype=torch.float32, device=sig.device)
+    call("osuf_frame_rows", _p(sig), sig.numel(), hop, K, _p(out), frames, _stream())
+    return out
+
+
+def log_vqt(wave_pad: torch.Tensor, bank: torch.Tensor, scale: torch.Tensor, hop: int, frames: int, eps: float = 1e-10,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[k][t] = log(scale[k] |sum_n wave_pad[t*hop+n] (bank[k][n] + i bank[bins+k][n])| + eps) -> (bins, frames) fp32 (audio.hip);
+    `out`: rows of a wider (bins_total, frames) result (row stride = its stride)."""
     assert wave_pad.is_cuda and wave_pad.dtype == torch.float32 and wave_pad.dim() == 1 and wave_pad.is_contiguous()
     assert bank.dtype == torch.float32 and bank.dim() == 2 and bank.is_contiguous() and bank.shape[0] % 2 == 0
     bins, K = bank.shape[0] // 2, bank.shape[1]
     assert scale.dtype == torch.float32 and scale.numel() == bins and hop % 4 == 0 and K % 4 == 0
     assert (frames - 1) * hop + K <= wave_pad.numel()
     ws = torch.empty((frames, 2 * bins), dtype=torch.float32, device=wave_pad.device)
-    out = torch.empty((bins, frames), dtype=torch.float32, device=wave_pad.device)
-    call("osuf_log_vqt", _p(wave_pad), wave_pad.numel(), _p(bank), K, bins, hop, _p(scale), eps, _p(ws), _p(out), frames, frames, _stream())
+    if out is None:
+        out = torch.empty((bins, frames), dtype=torch.float32, device=wave_pad.device)
+    assert out.dtype == torch.float32 and out.shape == (bins, frames) and out.stride(1) == 1
+    call("osuf_log_vqt", _p(wave_pad), wave_pad.numel(), _p(bank), K, bins, hop, _p(scale), eps, _p(ws), _p(out), out.stride(0), frames, _stream())
     return out

@@ -47,7 +47,8 @@ def test_every_attention_backward_kernel_vs_fp32_autograd(N):
     o, lse = ops.mqa_fwd(qkv, Bn, N, H, D, torch.bfloat16, D ** -0.5)
     assert rell2(o.float(), o_ref) < 5e-3                              # bf16 P and bf16 output rounding
     cases = [("auto", ops.ATTN_AUTO, 0), ("plain", ops.ATTN_PLAIN, 0), ("pipe-unsplit", ops.ATTN_PIPE, 1), ("pipe-split2", ops.ATTN_PIPE, 2),
-             ("pipe-split4", ops.ATTN_PIPE, 4), ("fused", ops.ATTN_FUSED, 0), ("fused-split2", ops.ATTN_FUSED, 2)]
+             ("pipe-split4", ops.ATTN_PIPE, 4), ("fused", ops.ATTN_FUSED, 0), ("fused-split2", ops.ATTN_FUSED, 2),
+             ("fused-slabs", ops.ATTN_FUSED_SLABS, 0)]
     outs = {}
     for name, variant, qsplit in cases:
         dqkv = ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5, variant=variant, qsplit=qsplit)
@@ -60,6 +61,8 @@ def test_every_attention_backward_kernel_vs_fp32_autograd(N):
         outs[name] = dqkv
     # the kernels differ only in schedule / summation order
     assert rell2(outs["plain"], outs["pipe-unsplit"]) < 2e-3
+    # the slab path adds the key blocks' partial dQ in a fixed order: bit-reproducible
+    assert torch.equal(outs["fused-slabs"], ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5, variant=ops.ATTN_FUSED_SLABS))
     # fused RoPE-transpose epilogue of the pipelined kernels == the stand-alone rope_bwd kernel on their fp32 result
     cos, sin = Fn.rope_tables(N, D, 2 * N, DEV)
     for name, variant, qsplit in cases[2:4] + cases[5:]:

@@ -34,5 +34,6 @@ for N in ([int(a) for a in sys.argv[1:]] or [4096, 2048, 1024, 512]):
     cos = sin = None
     t4 = timeit(lambda: ops.mqa_bwd(qkv, o, do, lse, B, N, H, D, D ** -0.5, torch.bfloat16, cos, sin, variant=ops.ATTN_FUSED))
     t5 = timeit(lambda: ops.mqa_bwd(qkv, o, do, lse, B, N, H, D, D ** -0.5, torch.bfloat16, cos, sin, variant=ops.ATTN_AUTO))
+    t6 = timeit(lambda: ops.mqa_bwd(qkv, o, do, lse, B, N, H, D, D ** -0.5, torch.bfloat16, cos, sin, variant=ops.ATTN_FUSED_SLABS))
     print(f"{N:6d} {t1:8.3f} {f / t1 / 1e9:6.0f} | {t2:8.3f} {1.5 * f / t2 / 1e9:6.0f} | {t3:8.3f} {2 * f / t3 / 1e9:6.0f} | {t4:8.3f} {2 * f / t4 / 1e9:8.0f}"
-          f"  [ops.mqa_bwd incl. delta + finish: fused {t4:.3f} ms vs pair {t5:.3f} ms]", flush=True)
+          f"  [ops.mqa_bwd incl. delta + finish: fused(atomics) {t4:.3f} ms, fused(slabs) {t6:.3f} ms, pair {t5:.3f} ms]", flush=True)
