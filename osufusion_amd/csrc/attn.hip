@@ -1048,6 +1048,11 @@ __global__ __launch_bounds__(512) void mqa_bwd_fused_kernel(AttnArgs a, float* d
   }
 }
 
+// (Tried and removed, round 2: the same sweep as 4 waves x 64 keys, one wave per SIMD with the whole 512-register file -- two 32-key
+//  halves per wave so that S / dP of one half overlap the exp / dS arithmetic of the other, Q / dO fragments read once per
+//  iteration for both halves.  Correct, but 9.95 ms per backward at B=32, N=4096 against 7.34 ms for the kernel above: past 256
+//  registers hipcc parks accumulators in AGPRs, and the loop spent 200 of its ~700 instructions on v_accvgpr_read / _mov / _write
+//  moving S, dP between the two halves of the file for the VALU.)
 // finishing pass of the fused backward's dQ: fp32 sums [M][H*64] -> scale, RoPE transpose (as store_grad_row), cast, into dq [M][lddq]
 template <typename TO>
 __global__ __launch_bounds__(256) void dq_finish_kernel(const float* __restrict__ dq32, TO* dq, long lddq, long M, int N, int H, float scale,
@@ -1365,12 +1370,12 @@ extern "C" int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk
 // stores are 32-byte pieces of 128-byte lines) or OSUF_DQ_SLABS (slabs in the output's element type, summed in a fixed order)
 // workspace = the dQ slabs / sums, followed, for query-split shapes, by the dK / dV partial sums of osuf_mqa_bwd_dkv
 static long fused_dq_bytes(int B, int H, int N, int out_dtype, int dq_mode) {
-  if (dq_mode == OSUF_DQ_ATOMIC) return (long)B * N * H * D * (long)sizeof(float);
+  if (dq_mode != OSUF_DQ_SLABS) return (long)B * N * H * D * (long)sizeof(float);
   const long npad = ((long)N + 31) / 32 * 32, nkb = ((long)N + 255) / 256;
   return ((nkb * B * npad * H * D * (out_dtype == OSUF_DT_BF16 ? 2 : 4)) + 15) / 16 * 16;
 }
 extern "C" long osuf_mqa_bwd_fused_workspace_bytes(int B, int H, int N, int out_dtype, int qsplit, int dq_mode) {
-  if (B <= 0 || H <= 0 || N <= 0 || qsplit < 0 || qsplit > 16 || (dq_mode != OSUF_DQ_SLABS && dq_mode != OSUF_DQ_ATOMIC)) return 0;
+  if (B <= 0 || H <= 0 || N <= 0 || qsplit < 0 || qsplit > 16 || (dq_mode != OSUF_DQ_ATOMIC && dq_mode != OSUF_DQ_SLABS)) return 0;
   return fused_dq_bytes(B, H, N, out_dtype, dq_mode) + osuf_mqa_bwd_dkv_workspace_bytes(B, N, qsplit);
 }
 
@@ -1383,7 +1388,7 @@ extern "C" int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long l
   if (rc) return rc;
   if (lddq % 8 || lddk % 8 || !al16(dq) || !al16(dk) || !al16(dv) || (out_dtype != OSUF_DT_F32 && out_dtype != OSUF_DT_BF16) ||
       ((rope_cos == nullptr) != (rope_sin == nullptr)) || qsplit < 0 || qsplit > 16 || !workspace || !al16(workspace) ||
-      (dq_mode != OSUF_DQ_SLABS && dq_mode != OSUF_DQ_ATOMIC) || workspace_bytes < osuf_mqa_bwd_fused_workspace_bytes(B, H, N, out_dtype, qsplit, dq_mode))
+      (dq_mode != OSUF_DQ_ATOMIC && dq_mode != OSUF_DQ_SLABS) || workspace_bytes < osuf_mqa_bwd_fused_workspace_bytes(B, H, N, out_dtype, qsplit, dq_mode))
     return OSUF_EINVAL;
   a.dk = dk; a.dv = dv; a.lddk = lddk; a.g_bf16 = out_dtype == OSUF_DT_BF16; a.rcos = rope_cos; a.rsin = rope_sin;
   const long M = (long)B * N;
@@ -1415,7 +1420,7 @@ extern "C" int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long l
   }
   const int qb = ew_grid(M * H * 8);
   const int nkb = (N + 255) / 256, npad = (N + 31) / 32 * 32;
-  if (dq_mode == OSUF_DQ_ATOMIC) {
+  if (dq_mode != OSUF_DQ_SLABS) {
     if (a.g_bf16) hipLaunchKernelGGL(dq_finish_kernel<bf16_t>, dim3(qb), dim3(256), 0, stream, dq32, (bf16_t*)dq, lddq, M, N, H, scale, rope_cos, rope_sin);
     else hipLaunchKernelGGL(dq_finish_kernel<float>, dim3(qb), dim3(256), 0, stream, dq32, (float*)dq, lddq, M, N, H, scale, rope_cos, rope_sin);
   } else if (a.g_bf16) {

@@ -380,11 +380,11 @@ class BlockFn(torch.autograd.Function):
     adapter (+ its parameters la, lb, lm as autograd inputs): LoRA / DoRA on the conv (block{1,2}.proj, trainer_peft.py:241)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, gamma, beta, ss, cache, adapter=None, la=None, lb=None, lm=None):
+    def forward(ctx, x, w, bias, gamma, beta, ss, cache, adapter=None, la=None, lb=None, lm=None, reslink=None):
         B, L, _ = x.shape
         C = w.shape[0]
         repro = ops.reproducible()                         # sampler: statistics by fixed-order reductions, not epilogue atomics
-        stats = None if repro else torch.zeros((B, 2), dtype=torch.float64, device=x.device)
+        stats = None if repro else ops.zeros((B, 2), torch.float64, x.device)
         if adapter is not None:
             weff, _ = adapter.effective()
             y = conv_forward(x, weff, bias, cache, "same", ("dora", *adapter.params), stats=stats)
@@ -395,7 +395,7 @@ class BlockFn(torch.autograd.Function):
         h = ops.gn_apply(y, mr, gamma, beta, ssc, L)
         ctx.save_for_backward(x, w, y, mr, gamma, beta, ssc if ssc is not None else mr)
         ctx.cache, ctx.has_ss, ctx.adapter = cache, ss is not None, adapter
-        ctx.bias_ref = bias
+        ctx.bias_ref, ctx.reslink = bias, reslink
         return h
 
     @staticmethod
@@ -435,13 +435,18 @@ class BlockFn(torch.autograd.Function):
             dgamma = dbeta = None
         dx = None
         if need[0]:
-            dx = conv_dgrad(dy, ad.effective()[0], ctx.cache, "same", L, vp=("dora", *ad.params)) if ad is not None \
-                else conv_dgrad(dy, w, ctx.cache, "same", L)
+            # + the gradient that reached x through the block's residual path (parked by GateRes*Fn.backward, see ResLink): it rides
+            # this GEMM's epilogue instead of a separate elementwise add over (B, L, C)
+            extra = None
+            if ctx.reslink is not None and ctx.reslink.dx is not None:
+                extra, ctx.reslink.dx = ctx.reslink.dx, None
+            dx = conv_dgrad(dy, ad.effective()[0], ctx.cache, "same", L, residual=extra, vp=("dora", *ad.params)) if ad is not None \
+                else conv_dgrad(dy, w, ctx.cache, "same", L, residual=extra)
         dw = conv_wgrad(dy, x, w, "same") if need[1] else None
         da = dlb = dm = None
         if ad is not None and (need[8] or need[9] or need[10]):
             da, dlb, dm = adapter_grads(ad, dy, x, y, ctx.bias_ref, "same", ctx.cache, sums=(dyy, sdy) if want_dm else None)
-        return dx, dw, db, dgamma if need[3] else None, dbeta if need[4] else None, dss, None, None, da, dlb, dm
+        return dx, dw, db, dgamma if need[3] else None, dbeta if need[4] else None, dss, None, None, da, dlb, dm, None
 
 
 class GateLink:
@@ -454,6 +459,17 @@ class GateLink:
 
     def __init__(self) -> None:
         self.dout = self.gate = None
+
+
+class ResLink:
+    """Per-forward hand-off of the residual path's input gradient inside one ResidualBlock (residual.py:137: h + res_conv(x)): x
+    feeds both block1's convolution and the residual add, so autograd would add two (B, L, C) gradients with an elementwise kernel.
+    GateRes*Fn.backward (it runs first: it is downstream of block1) parks its contribution here and returns none for x; block1's
+    BlockFn.backward then passes it as the residual operand of its input-gradient GEMM (added in the epilogue)."""
+    __slots__ = ("dx",)
+
+    def __init__(self) -> None:
+        self.dx = None
 
 
 class GCAPoolFn(torch.autograd.Function):
@@ -505,11 +521,11 @@ class GateResFn(torch.autograd.Function):
     """out = h * gate + res   (residual.py:135-137, identity res_conv).  gate fp32 (B, C)."""
 
     @staticmethod
-    def forward(ctx, h, gate, res, link=None):
+    def forward(ctx, h, gate, res, link=None, rlink=None):
         L = h.shape[1]
         gate = gate.contiguous()
         ctx.save_for_backward(h, gate)
-        ctx.link = link
+        ctx.link, ctx.rlink = link, rlink
         return ops.gate_residual(h, gate, res, L)
 
     @staticmethod
@@ -518,17 +534,20 @@ class GateResFn(torch.autograd.Function):
         B, L, C = h.shape
         dout = _rc(dout)
         dgate = ops.wcolsum(dout, h, None, B, L)
-        return _gate_dh(ctx.link, dout, gate, L), dgate, dout, None
+        dres = dout
+        if ctx.rlink is not None and ctx.needs_input_grad[2]:
+            ctx.rlink.dx, dres = dout, None
+        return _gate_dh(ctx.link, dout, gate, L), dgate, dres, None, None
 
 
 class GateResConvFn(torch.autograd.Function):
     """out = h * gate + res_conv(x)  (residual.py:135-137, 1x1 res_conv): the gate-multiply rides the GEMM epilogue."""
 
     @staticmethod
-    def forward(ctx, h, gate, x, w, bias, cache, link=None):
+    def forward(ctx, h, gate, x, w, bias, cache, link=None, rlink=None):
         gate = gate.contiguous()
         ctx.save_for_backward(h, gate, x, w)
-        ctx.cache, ctx.bias_ref, ctx.link = cache, bias, link
+        ctx.cache, ctx.bias_ref, ctx.link, ctx.rlink = cache, bias, link, rlink
         return conv_forward(x, w, bias, cache, "same", None, residual=h, rscale=gate)
 
     @staticmethod
@@ -538,10 +557,12 @@ class GateResConvFn(torch.autograd.Function):
         dout = _rc(dout)
         dgate = ops.wcolsum(dout, h, None, B, L)
         dh = _gate_dh(ctx.link, dout, gate, L)
-        dx = conv_dgrad(dout, w, ctx.cache, "same", L)
+        dx = conv_dgrad(dout, w, ctx.cache, "same", L) if ctx.needs_input_grad[2] else None
+        if ctx.rlink is not None and dx is not None:
+            ctx.rlink.dx, dx = dx, None
         dw = conv_wgrad(dout, x, w, "same") if ctx.needs_input_grad[3] else None
         db = _bias_grad(dout, ctx.bias_ref) if ctx.needs_input_grad[4] else None
-        return dh, dgate, dx, dw, db, None, None
+        return dh, dgate, dx, dw, db, None, None, None
 
 
 class FeedForwardFn(torch.autograd.Function):

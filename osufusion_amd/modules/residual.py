@@ -54,10 +54,10 @@ class Block(nn.Module):
         self.activation = nn.SiLU()
         self._cache = Fn.PackCache()
 
-    def forward_rows(self, x: torch.Tensor, ss: Optional[torch.Tensor]) -> torch.Tensor:
-        extra = self.proj.adapter_inputs() if hasattr(self.proj, "adapter_inputs") else ()      # lora_layers.LoraConv1d
+    def forward_rows(self, x: torch.Tensor, ss: Optional[torch.Tensor], reslink=None) -> torch.Tensor:
+        extra = self.proj.adapter_inputs() if hasattr(self.proj, "adapter_inputs") else (None, None, None, None)  # lora_layers.LoraConv1d
         with scope("Residual's Block"):                    # residual.py:86
-            return Fn.BlockFn.apply(x, self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias, ss, self._cache, *extra)
+            return Fn.BlockFn.apply(x, self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias, ss, self._cache, *extra, reslink)
 
     def forward(self, x: torch.Tensor, scale_shift: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
         rows = rt.to_rows(x, rt.compute_dtype(self.proj.weight.dtype))
@@ -95,13 +95,14 @@ class ResidualBlock(nn.Module):
             emb = rt.shared_cat(t, c)                      # cat(t, c): one tensor for all blocks of a forward
             lin = self.mlp[1]
             ss = rt.small_linear(emb, lin.weight, lin.bias, in_act=ops.ACT_SILU)          # (B, 2C): scale | shift
-        h = self.block1.forward_rows(x, ss)
+        rlink = Fn.ResLink() if torch.is_grad_enabled() and x.requires_grad else None      # residual-path gradient -> block1's dgrad
+        h = self.block1.forward_rows(x, ss, rlink)
         h = self.block2.forward_rows(h, None)
         link = Fn.GateLink() if torch.is_grad_enabled() and h.requires_grad else None
         gate = self.se.gate_from_rows(h, link)
         if isinstance(self.res_conv, nn.Identity):
-            return Fn.GateResFn.apply(h, gate, x, link)
-        return Fn.GateResConvFn.apply(h, gate, x, self.res_conv.weight, self.res_conv.bias, self._cr, link)
+            return Fn.GateResFn.apply(h, gate, x, link, rlink)
+        return Fn.GateResConvFn.apply(h, gate, x, self.res_conv.weight, self.res_conv.bias, self._cr, link, rlink)
 
     def forward(self, x: torch.Tensor, t: Optional[torch.Tensor] = None, c: Optional[torch.Tensor] = None) -> torch.Tensor:
         rows = rt.to_rows(x, rt.compute_dtype(self.block1.proj.weight.dtype))

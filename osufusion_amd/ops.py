@@ -88,6 +88,57 @@ def set_kernel_timer(t: Optional[KernelTimer]) -> None:
     _TIMER = t
 
 
+class ZeroArena:
+    """Pre-zeroed scratch for one train step.  The kernels' accumulators (GroupNorm statistics and backward sums, pooling / bias
+    column sums, the loss) each used to be a `torch.zeros` = an allocation plus a fill launch -- ~380 fills per step.  Inside a
+    Trainer step they are bump-allocated from one device buffer that is cleared by ONE fill at the start of the next step (up to the
+    previous high-water mark); nothing handed out is reused before then, so tensors saved for backward stay valid."""
+
+    ALIGN = 256
+
+    def __init__(self, device, nbytes: int = 192 << 20) -> None:
+        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        self.off = 0
+        self.dirty = 0                                     # bytes handed out since the last clear
+        self.misses = 0
+
+    def begin(self) -> None:
+        if self.dirty:
+            self.buf[: self.dirty].zero_()
+        self.off = self.dirty = 0
+
+    def take(self, shape, dtype: torch.dtype) -> Optional[torch.Tensor]:
+        n = 1
+        for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
+            n *= int(d)
+        nbytes = n * torch.empty(0, dtype=dtype).element_size()
+        end = self.off + (nbytes + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        if end > self.buf.numel():
+            self.misses += 1
+            return None
+        t = self.buf[self.off: self.off + nbytes].view(dtype).view(shape)
+        self.off = self.dirty = end
+        return t
+
+
+_ARENA: Optional[ZeroArena] = None
+
+
+def set_zero_arena(arena: Optional[ZeroArena]) -> None:
+    """Trainer.step activates its arena for the duration of forward + backward; None = plain torch.zeros."""
+    global _ARENA
+    _ARENA = arena
+
+
+def zeros(shape, dtype: torch.dtype, device) -> torch.Tensor:
+    """A zero-initialised accumulator: from the active step arena when there is one (and it is on `device`), else torch.zeros."""
+    if _ARENA is not None and _ARENA.buf.device == torch.device(device):
+        t = _ARENA.take(shape, dtype)
+        if t is not None:
+            return t
+    return torch.zeros(shape, dtype=dtype, device=device)
+
+
 def call(name: str, *args, meta=None) -> None:
     lib = _lib.load()
     if _TIMER is not None and name in _TIMER.names:
@@ -176,7 +227,7 @@ def colsum(y: torch.Tensor, n: Optional[int] = None, out: Optional[torch.Tensor]
     M, N, ld = _rows(y)
     N = N if n is None else n
     if out is None:
-        out = torch.zeros(N, dtype=torch.float32, device=y.device)
+        out = zeros(N, torch.float32, y.device)
     call("osuf_colsum", dt_of(y), _p(y), ld, M, N, _p(out), _stream())
     return out
 
@@ -219,11 +270,11 @@ def gn_bwd(dh: torch.Tensor, y: torch.Tensor, mr: torch.Tensor, gamma: torch.Ten
     B = M // L
     dev = y.device
     dy = torch.empty(y.shape, dtype=y.dtype, device=dev)
-    T12 = torch.zeros((B, 4, C), dtype=torch.float32, device=dev)
+    T12 = zeros((B, 4, C), torch.float32, dev)
     S = torch.empty((B, 2), dtype=torch.float32, device=dev)
     dss = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if ss is not None else None
     if dgamma_out is None or dbeta_out is None:
-        dgb = torch.zeros((2, C), dtype=torch.float32, device=dev)
+        dgb = zeros((2, C), torch.float32, dev)
         dgamma_out, dbeta_out = dgb[0], dgb[1]
     call("osuf_gn_bwd", dt_of(y), _p(dh), _rows(dh)[2], _p(y), ldy, _p(dy), C, _p(mr), _p(gamma), _p(beta), _p(ss), _p(T12), _p(S),
          _p(dss), _p(dgamma_out), _p(dbeta_out), _p(dbias_out), _p(dyy_out), M, C, L, _stream())
@@ -268,7 +319,7 @@ def wcolsum(a: torch.Tensor, bmul: Optional[torch.Tensor], w: Optional[torch.Ten
         out = torch.empty((B, C), dtype=torch.float32, device=a.device)
         part = torch.empty((B, (L + 63) // 64, C), dtype=torch.float32, device=a.device)
     else:
-        out = torch.zeros((B, C), dtype=torch.float32, device=a.device)
+        out = zeros((B, C), torch.float32, a.device)
     call("osuf_wcolsum", dt_of(a), _p(a), ld, _p(bmul), _rows(bmul)[2] if bmul is not None else 0, _p(w), _p(out), B, C, L, _p(part), _stream())
     return out
 
@@ -338,7 +389,7 @@ def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Ten
     kp, vp, ldo_ = base + 2 * H * D, base + 2 * (H + 1) * D, _rows(do)[2]
     call("osuf_attn_delta", _p(do), ldo_, _p(o), _rows(o)[2], _DT[o.dtype], _p(delta), B, H, N, D, _stream())
     if variant in (ATTN_FUSED, ATTN_FUSED_SLABS):
-        mode = 1 if variant == ATTN_FUSED_SLABS else 0
+        mode = 1 if variant == ATTN_FUSED_SLABS else 0                            # OSUF_DQ_SLABS / OSUF_DQ_ATOMIC
         need = _lib.load().osuf_mqa_bwd_fused_workspace_bytes(B, H, N, _DT[out_dtype], qsplit, mode)
         ws = _workspace(need, qkv.device)
         call("osuf_mqa_bwd_fused", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase, W, gbase + es * H * D,
@@ -411,7 +462,7 @@ def ddim_step(x: torch.Tensor, cond: torch.Tensor, null: Optional[torch.Tensor],
 def mse(pred: torch.Tensor, target: torch.Tensor, orig_len: Optional[torch.Tensor], want_grad: bool):
     B, Dc, Lx = pred.shape
     grad = torch.empty_like(pred) if want_grad else None
-    acc = torch.zeros(1, dtype=torch.float64, device=pred.device)
+    acc = zeros(1, torch.float64, pred.device)
     ol = orig_len.to(device=pred.device, dtype=torch.int32).contiguous() if orig_len is not None else None
     call("osuf_mse", _p(pred), _p(target), _p(ol), _p(grad), _p(acc), B, Dc, Lx, _stream())
     return acc, grad

@@ -85,12 +85,15 @@ class FlatParameters:
 class GradReducer:
     """Bucketed, overlapped gradient all-reduce over the flat gradient buffer (the DDP semantics of trainer.py:264-269,301).
 
-    A bucket is a contiguous slice of the flat gradient buffer; it is all-reduced (async, SUM) the moment its last parameter
-    reports a complete gradient -- by the kernels' direct-accumulation path (`param_ready`) or by autograd's
-    post-accumulate-grad hook.  A parameter must report ONCE per backward: a second report (a module applied twice, tied
-    weights) would mean the first one was premature and the bucket may already be on the wire, so it raises; train such models
-    with overlap=False (every bucket is reduced in finish()).  `begin(sync=False)` makes a backward a no-sync micro-step of
-    gradient accumulation (`accelerator.accumulate`, trainer.py:293-295): reports are ignored, nothing is sent."""
+    A bucket is a contiguous slice of the flat gradient buffer; it is all-reduced (async, SUM) the moment its last parameter's
+    gradient is complete.  "Complete" is autograd's post-accumulate-grad hook and nothing else: measured on the GPU
+    (tools/check_grad_reports.py, torch 2.10) the hook fires for EVERY parameter of the graph -- also for those whose gradient the
+    HIP kernels added straight into the flat buffer while the autograd Function returned None -- and it fires once, after the LAST
+    use of the parameter has run its backward (a module applied twice, tied weights: still one hook, after both).  The kernels'
+    own notification (functional.grad_done -> param_ready) always comes earlier and says only "one use is done", so it is recorded
+    for diagnostics and never launches a bucket (round 1 launched on whichever came first: premature for a re-used parameter).
+    `begin(sync=False)` makes a backward a no-sync micro-step of gradient accumulation (`accelerator.accumulate`,
+    trainer.py:293-295): nothing is sent.  overlap=False reduces every bucket in finish()."""
 
     def __init__(self, flat: FlatParameters, bucket_mib: float = 64.0, group=None, overlap: bool = True) -> None:
         self.flat, self.group, self.bucket_mib, self.overlap = flat, group, bucket_mib, overlap
@@ -102,6 +105,8 @@ class GradReducer:
         self.order_log: List[int] = []                     # parameter indices in the order they completed (last backward)
         self.fired_early: List[int] = []                   # buckets launched from a completion report (before finish())
         self._hooked = set()
+        self.names = {}                                    # id(param) -> name, filled by Trainer for error messages
+        self.direct_reports = 0
         self._done = set()
         self._fresh = True                                 # the next completion report opens a new backward
         self.rebuild()
@@ -146,10 +151,8 @@ class GradReducer:
         self._fresh = False
 
     def param_ready(self, p) -> None:
-        """Called by the kernels' direct-accumulation path (functional.grad_done): the gradient of `p` is complete."""
-        idx = self._index.get(id(p))
-        if idx is not None:
-            self._ready(idx)
+        """functional.grad_done: one direct-accumulation kernel for `p` has been launched.  Diagnostic only (see the class note)."""
+        self.direct_reports += 1
 
     def _hook(self, param) -> None:
         idx = self._index.get(id(param))
@@ -159,12 +162,9 @@ class GradReducer:
     def _ready(self, idx: int) -> None:
         if self._fresh:                                    # first report after a finish(): a new backward (begin() is optional)
             self._open()
-        if idx in self._seen:
-            if self.enabled and self.sync and self.overlap:
-                raise RuntimeError(
-                    f"parameter #{idx} {tuple(self.flat.params[idx].shape)} reported a complete gradient twice in one backward "
-                    "(module applied twice / tied weights): its bucket may already be in flight -- use Trainer(overlap=False)")
-            return
+        if idx in self._seen:                              # cannot happen within one backward (one AccumulateGrad node per parameter)
+            who = self.names.get(id(self.flat.params[idx]), f"#{idx}")
+            raise RuntimeError(f"parameter {who}: second post-accumulate-grad hook in one backward -- call begin() between backwards")
         self._seen.add(idx)
         self.order_log.append(idx)
         if not (self.enabled and self.sync and self.overlap):
@@ -288,12 +288,14 @@ class Trainer:
         self.model = model
         self.flat = FlatParameters(model)
         self.reducer = GradReducer(self.flat, bucket_mib, overlap=overlap)
+        self.reducer.names = {id(p): n for n, p in model.named_parameters()}
         self.opt = FusedAdamW(self.flat, lr=lr, weight_decay=weight_decay)
         self.clip = clip_grad_norm
         self.compute_dtype = compute_dtype
         self.accum = gradient_accumulation_steps
         self.micro = 0                                      # micro-batches accumulated since the last optimizer step
         self._reorder_pending = reorder_buckets
+        self.arena = ops.ZeroArena(self.flat.data.device) if self.flat.data.is_cuda else None
         if self.reducer.enabled:                            # identical replicas (guard; inits are already deterministic)
             dist.broadcast(self.flat.data, src=0)
         Fn.bump_weight_epoch()
@@ -307,12 +309,18 @@ class Trainer:
             self.flat.zero_grad()
         last = self.micro + 1 == self.accum
         self.reducer.begin(sync=last)
-        with forced_compute_dtype(self.compute_dtype):
-            if noise is None:
-                loss = self.model(x, a, c, orig_len)
-            else:
-                loss = self.model.loss_with(x, a, c, noise, timesteps, orig_len)
-            loss.backward()
+        if self.arena is not None:
+            self.arena.begin()                              # one fill clears what the previous step's accumulators dirtied
+        ops.set_zero_arena(self.arena)
+        try:
+            with forced_compute_dtype(self.compute_dtype):
+                if noise is None:
+                    loss = self.model(x, a, c, orig_len)
+                else:
+                    loss = self.model.loss_with(x, a, c, noise, timesteps, orig_len)
+                loss.backward()
+        finally:
+            ops.set_zero_arena(None)
         self.reducer.finish()
         self.micro += 1
         if not last:

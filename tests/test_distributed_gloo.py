@@ -183,24 +183,23 @@ def _worker_double_report(rank, world, port, out):
         model(xs).square().mean().backward()
         red.finish()
         mine = flat.grad.clone()
-        # (b) the kernels' direct-accumulation path reporting one parameter twice must not pass silently
+        # (b) the kernels' own "one use done" notification never launches a bucket, however often it comes: only the hook does
         flat.zero_grad()
         red.begin()
-        red.param_ready(flat.params[0])
-        raised = False
-        try:
-            red.param_ready(flat.params[0])
-        except RuntimeError as e:
-            raised = "twice" in str(e)
+        for p in flat.params:
+            red.param_ready(p)
+            red.param_ready(p)
+        raised = red.fired_early == [] and red.handles == [] and red.direct_reports == 2 * len(flat.params)
+        model(xs).square().mean().backward()
+        assert len(red.fired_early) == len(red.bounds)               # one hook per parameter, after BOTH uses of the shared layer
         red.finish()
-        # (c) ... and is accepted without overlap: everything is reduced in finish()
+        assert torch.allclose(flat.grad, mine, rtol=1e-6, atol=1e-8)
+        # (c) without overlap everything is reduced in finish()
         red.enabled = False                                        # its hooks stay registered on the parameters: silence it
         red2 = GradReducer(flat, bucket_mib=0.0001, overlap=False)
         flat.zero_grad()
         red2.begin()
         model(xs).square().mean().backward()
-        red2.param_ready(flat.params[0])
-        red2.param_ready(flat.params[0])
         assert red2.fired_early == []
         red2.finish()
         out[rank] = (mine, raised, flat.grad.clone())
@@ -209,7 +208,7 @@ def _worker_double_report(rank, world, port, out):
 
 
 @pytest.mark.timeout(120)
-def test_parameter_reporting_twice_is_refused_when_overlapping():
+def test_shared_module_and_direct_notifications():
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
