@@ -128,6 +128,7 @@ def main() -> None:
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the extra fp32-compute-mode step (the mode in which the 1e-3 parity bound holds)")
     ap.add_argument("--attn-bwd", choices=["auto", "pair", "fused", "slabs"], default="auto",
                     help="attention backward: auto = the library default (fused sweep, atomic dQ); pair = dQ + dK/dV kernels; slabs = fused, fixed-order dQ")
+    ap.add_argument("--no-fuse-rowdot", action="store_true", help="A/B: sum(dO*O) by the stand-alone pass instead of the to_out dgrad epilogue")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,6 +157,8 @@ def main() -> None:
         with torch.no_grad():                              # peft zero-inits lora_B: give it life so every adapter gradient is exercised
             for m in LL.lora_modules(model):
                 m.lora_B["default"].weight.normal_(0.0, 0.02)
+    if args.no_fuse_rowdot:
+        ops.FUSE_ROWDOT = False
     if args.attn_bwd != "auto":
         ops.ATTN_BWD_DEFAULT = {"fused": ops.ATTN_FUSED, "slabs": ops.ATTN_FUSED_SLABS, "pair": ops.ATTN_AUTO}[args.attn_bwd]
     trainer = Trainer(model, lr=1e-4, weight_decay=1e-2, clip_grad_norm=1.0, compute_dtype=torch.bfloat16)

@@ -52,6 +52,13 @@ int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, long ldw, lo
                  int M, int N, int K, int taps, int Lin, int Lout, int stride, int pad, int mode, int act,
                  hipStream_t stream);
 
+/* C = A W^T (one tap, no bias, no activation) and, from the same epilogue, the row constants of the flash backward:
+ *   delta[b][h][l] = sum_{d < 64} bf16(C[b*L + l][h*64 + d]) * O[b*L + l][h*64 + d]            (N = heads * 64, M % L == 0)
+ * replaces: autograd's input-gradient of Attention.to_out (modules/unet.py:123,141) + the sum(dO * O) pass of SDPA's backward
+ * (attention.py:94-99) -- i.e. osuf_gemm_nt followed by osuf_attn_delta, without re-reading dO and O. */
+int osuf_gemm_nt_rowdot(int dtype, const void* A, long lda, const void* W, long ldw, void* C, long ldc, const void* O, long ldo,
+                        float* delta, int M, int N, int K, int L, int heads, hipStream_t stream);
+
 /* dW (+)= sum_m dY[m][n1] * X[rowmap(m,t)][n2].  out_layout 0: dW[t][n1][n2] with row stride ldw and tap stride tapstride;
  * out_layout 1: dense dW[n1][n2][t], i.e. torch's (Cout, Cin, k) Conv1d weight layout, so the gradient can be accumulated
  * straight into the parameter's .grad.  accumulate 1: add into dW; 0: overwrite (no zero-init needed by the caller).

@@ -20,6 +20,7 @@ P, L, I, F = c_void_p, c_long, c_int, c_float
 SIGNATURES = {
     "osuf_version": [],
     "osuf_gemm_nt": [I, P, L, P, L, L, P, L, P, L, P, L, P, L, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "osuf_gemm_nt_rowdot": [I, P, L, P, L, P, L, P, L, P, I, I, I, I, I, P],
     "osuf_gemm_tn": [I, P, L, P, L, P, L, L, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P],
     "osuf_gemm_tn_workspace_bytes": [I, I, I, I, I],
     "osuf_colsum": [I, P, L, I, I, P, P],

@@ -41,6 +41,7 @@ __device__ __forceinline__ int map_row(const RowMap& rm, int i, int t) {
 struct GemmArgs {
   const void* A; const void* W; void* C; void* C2; const void* R; const void* U;
   const float* bias; const float* rscale; double* stats;
+  float* delta; int heads;         // osuf_gemm_nt_rowdot: R is not added but dotted, per 64-column head, with the bf16-rounded output
   long lda, ldw, tapstride, ldc, ldc2, ldr, ldu;
   int M, N, K, taps;
   RowMap rm;
@@ -117,7 +118,13 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&a
       if (R) {
         float rr[4];
         load4(R + (long)m * g.ldr + n, rr);
-        if (g.rscale) {
+        if (g.delta) {                  // delta[b][head][pos] = sum over the head's 64 columns (16 lanes) of bf16(C) * R
+          float part = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) part += round_bf16(v[e]) * rr[e];
+          part = group_sum<16>(part);
+          if ((tid & 15) == 0) g.delta[((long)bidx * g.heads + (n >> 6)) * g.rm.Lout + (m - bidx * g.rm.Lout)] = part;
+        } else if (g.rscale) {
           f32x4 sc = *reinterpret_cast<const f32x4*>(g.rscale + (long)bidx * g.N + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += rr[e] * sc[e];
@@ -458,7 +465,7 @@ __device__ __forceinline__ void gemm_big_epilogue_impl(const GemmArgs& g, f32x16
     __builtin_amdgcn_wave_barrier();
     // sample index of this lane's row, carried across the passes (+8 rows each) instead of one integer division per pass
     int bidx = 0, bpos = 0;
-    if (g.stats != nullptr || g.rscale != nullptr) {
+    if (g.stats != nullptr || g.rscale != nullptr || g.delta != nullptr) {
       const int mfirst = m0 + wr * 128 + half * 64 + prow;
       bidx = mfirst / g.rm.Lout;
       bpos = mfirst - bidx * g.rm.Lout;
@@ -501,7 +508,13 @@ __device__ __forceinline__ void gemm_big_epilogue_impl(const GemmArgs& g, f32x16
           float rr[8];
           if constexpr (MODE == 1) unpack(pre[it], rr);
           else load8(R + (long)m * g.ldr + n, rr);
-          if (g.rscale) {
+          if (g.delta) {                // as in gemm_epilogue_impl; a head's 64 columns are this row's 8 lanes
+            float part = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part += round_bf16(v[e]) * rr[e];
+            part = group_sum<8>(part);
+            if ((lane & 7) == 0) g.delta[((long)bidx * g.heads + (n >> 6)) * g.rm.Lout + bpos] = part;
+          } else if (g.rscale) {
             float sc[8];
             load8(g.rscale + (long)bidx * g.N + n, sc);
 #pragma unroll
@@ -1350,11 +1363,36 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* Y, long ldy, int M
 // ---------------------------------------------------------------------------------------------------------
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+static int gemm_nt_launch(int dtype, const void* A, long lda, const void* W, long ldw, long tapstride,
+                          void* C, long ldc, void* C2, long ldc2, const void* R, long ldr, const void* U, long ldu,
+                          const float* bias, const float* rscale, double* stats,
+                          int M, int N, int K, int taps, int Lin, int Lout, int stride, int pad, int mode, int act,
+                          float* delta, int heads, hipStream_t stream);
+
 extern "C" int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, long ldw, long tapstride,
                             void* C, long ldc, void* C2, long ldc2, const void* R, long ldr, const void* U, long ldu,
                             const float* bias, const float* rscale, double* stats,
                             int M, int N, int K, int taps, int Lin, int Lout, int stride, int pad, int mode, int act,
                             hipStream_t stream) {
+  return gemm_nt_launch(dtype, A, lda, W, ldw, tapstride, C, ldc, C2, ldc2, R, ldr, U, ldu, bias, rscale, stats, M, N, K, taps, Lin, Lout,
+                        stride, pad, mode, act, nullptr, 0, stream);
+}
+
+// C = A W^T (one tap, no bias) and, from the same epilogue, delta[b][h][l] = sum_{d < 64} bf16(C[b*L + l][h*64 + d]) * O[b*L + l][h*64 + d]:
+// the to_out input-gradient GEMM of the attention block hands the flash backward its row constants (sum_d dO * O) without a
+// second pass over dO and O.  N = heads * 64; M % L == 0.
+extern "C" int osuf_gemm_nt_rowdot(int dtype, const void* A, long lda, const void* W, long ldw, void* C, long ldc, const void* O, long ldo,
+                                   float* delta, int M, int N, int K, int L, int heads, hipStream_t stream) {
+  if (!O || !delta || heads <= 0 || N != heads * 64 || L <= 0 || !aligned16(O) || ldo % 8) return OSUF_EINVAL;
+  return gemm_nt_launch(dtype, A, lda, W, ldw, 0, C, ldc, nullptr, 0, O, ldo, nullptr, 0, nullptr, nullptr, nullptr, M, N, K, 1, L, L, 1, 0, 0, 0,
+                        delta, heads, stream);
+}
+
+static int gemm_nt_launch(int dtype, const void* A, long lda, const void* W, long ldw, long tapstride,
+                          void* C, long ldc, void* C2, long ldc2, const void* R, long ldr, const void* U, long ldu,
+                          const float* bias, const float* rscale, double* stats,
+                          int M, int N, int K, int taps, int Lin, int Lout, int stride, int pad, int mode, int act,
+                          float* delta, int heads, hipStream_t stream) {
   const int epc = dtype == OSUF_DT_BF16 ? 8 : 4;
   if (dtype != OSUF_DT_BF16 && dtype != OSUF_DT_F32) return OSUF_EUNSUPPORTED;
   if (M <= 0 || N <= 0 || K <= 0 || taps <= 0 || Lout <= 0 || Lin <= 0) return OSUF_EINVAL;
@@ -1365,6 +1403,7 @@ extern "C" int osuf_gemm_nt(int dtype, const void* A, long lda, const void* W, l
   if ((long)(M / Lout) * Lin >= (1L << 31)) return OSUF_EINVAL;
   GemmArgs g;
   g.A = A; g.W = W; g.C = C; g.C2 = C2; g.R = R; g.U = U; g.bias = bias; g.rscale = rscale; g.stats = stats;
+  g.delta = delta; g.heads = heads;
   g.lda = lda; g.ldw = ldw; g.tapstride = tapstride; g.ldc = ldc; g.ldc2 = ldc2; g.ldr = ldr; g.ldu = ldu;
   g.M = M; g.N = N; g.K = K; g.taps = taps;
   g.rm = RowMap{Lin, Lout, stride, pad, mode};

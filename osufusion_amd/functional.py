@@ -664,11 +664,14 @@ class AttentionFn(torch.autograd.Function):
         dwo = conv_wgrad(dout, o, wo, "same") if need[5] else None
         dbo = _bias_grad(dout, ctx.bo) if need[6] else None
         wdo = cache.packs(("po", dt), (wo,), wo, "same", dt)[1]
-        do = ops.gemm_nt(dout, wdo, None, out_shape=o.shape)
+        if ops.FUSE_ROWDOT:
+            do, delta = ops.gemm_nt_rowdot(dout, wdo, o, N, H)                   # dO and sum_d dO * O from one epilogue
+        else:
+            do, delta = ops.gemm_nt(dout, wdo, None, out_shape=o.shape), None
         do16 = ops.cast_rows(do, torch.bfloat16)                                 # SDPA backward runs in bf16 (attention.py:101)
         # attention + rope
         cos, sin = rope_tables(N, D, scale_base, x.device)
-        dqkv = ops.mqa_bwd(qkv_r, o, do16, lse, B, N, H, D, scale, dt, cos, sin, variant=ops.ATTN_BWD_DEFAULT)  # RoPE transpose + cast ride the kernels' epilogues
+        dqkv = ops.mqa_bwd(qkv_r, o, do16, lse, B, N, H, D, scale, dt, cos, sin, variant=ops.ATTN_BWD_DEFAULT, delta=delta)  # RoPE transpose + cast ride the kernels' epilogues
         # to_q / to_kv
         dwq = conv_wgrad(dqkv[..., : H * D], xn, wq, "same") if need[3] else None
         dwkv = conv_wgrad(dqkv[..., H * D:], xn, wkv, "same") if need[4] else None

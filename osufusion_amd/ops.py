@@ -184,6 +184,19 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return (out, pre) if want_pre else out
 
 
+def gemm_nt_rowdot(a: torch.Tensor, w: torch.Tensor, o: torch.Tensor, L: int, heads: int):
+    """(C, delta): C = a @ w[0].T (rows [M][heads*64], a's dtype) and delta[b][h][l] = sum_d bf16(C) * o over each head's 64 columns."""
+    M, K, lda = _rows(a)
+    w3 = w if w.dim() == 3 else w.unsqueeze(0)
+    assert w3.dtype == a.dtype and w3.is_contiguous() and w3.shape[0] == 1 and w3.shape[2] == K and w3.shape[1] == heads * 64
+    Mo, No, ldo = _rows(o)
+    assert Mo == M and No == heads * 64 and o.dtype == a.dtype and M % L == 0
+    out = torch.empty(o.shape, dtype=a.dtype, device=a.device)
+    delta = torch.empty((M // L, heads, L), dtype=torch.float32, device=a.device)
+    call("osuf_gemm_nt_rowdot", dt_of(a), _p(a), lda, _p(w3), K, _p(out), heads * 64, _p(o), ldo, _p(delta), M, heads * 64, K, L, heads, _stream())
+    return out, delta
+
+
 def gemm_tn(dy: torch.Tensor, x: torch.Tensor, *, taps: int = 1, lin: Optional[int] = None, lout: Optional[int] = None, stride: int = 1,
             pad: int = 0, mode: int = 0, n1: Optional[int] = None, out: Optional[torch.Tensor] = None, conv_layout: bool = False,
             accumulate: bool = False) -> torch.Tensor:
@@ -374,20 +387,22 @@ ATTN_AUTO, ATTN_PLAIN, ATTN_PIPE, ATTN_FUSED, ATTN_FUSED_SLABS = 0, 1, 2, 3, 4
 # What AttentionFn.backward asks for: ATTN_FUSED = one key-stationary sweep, dQ by fp32 atomics (fastest at every UNet shape, measured
 # round 2); ATTN_FUSED_SLABS = the same sweep with a fixed-order dQ sum (bit-reproducible); ATTN_AUTO = the dQ + dK/dV kernel pair.
 ATTN_BWD_DEFAULT = ATTN_FUSED
+FUSE_ROWDOT = True      # AttentionFn.backward: sum_d dO * O from the to_out dgrad GEMM's epilogue (False: the stand-alone osuf_attn_delta pass)
 
 
 def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, D: int, scale: float,
             out_dtype: torch.dtype = torch.float32, cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None,
-            variant: int = ATTN_AUTO, qsplit: int = 0) -> torch.Tensor:
+            variant: int = ATTN_AUTO, qsplit: int = 0, delta: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Gradients laid out like qkv, [B*N][(H+2)*D], in out_dtype.  With the RoPE tables (N, D/2) the q / k gradients are those of
     the un-rotated projections (the rotation's transpose is applied in the kernels' epilogues)."""
     M, W, ld = _rows(qkv)
     assert do.dtype == torch.bfloat16
     dqkv = torch.empty((B, N, W), dtype=out_dtype, device=qkv.device)
-    delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     base, gbase, es = qkv.data_ptr(), dqkv.data_ptr(), dqkv.element_size()
     kp, vp, ldo_ = base + 2 * H * D, base + 2 * (H + 1) * D, _rows(do)[2]
-    call("osuf_attn_delta", _p(do), ldo_, _p(o), _rows(o)[2], _DT[o.dtype], _p(delta), B, H, N, D, _stream())
+    if delta is None:                                      # (B, H, N) sum_d dO * O: given when the to_out dgrad GEMM produced it
+        delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+        call("osuf_attn_delta", _p(do), ldo_, _p(o), _rows(o)[2], _DT[o.dtype], _p(delta), B, H, N, D, _stream())
     if variant in (ATTN_FUSED, ATTN_FUSED_SLABS):
         mode = 1 if variant == ATTN_FUSED_SLABS else 0                            # OSUF_DQ_SLABS / OSUF_DQ_ATOMIC
         need = _lib.load().osuf_mqa_bwd_fused_workspace_bytes(B, H, N, _DT[out_dtype], qsplit, mode)

@@ -162,9 +162,12 @@ class GradReducer:
     def _ready(self, idx: int) -> None:
         if self._fresh:                                    # first report after a finish(): a new backward (begin() is optional)
             self._open()
-        if idx in self._seen:                              # cannot happen within one backward (one AccumulateGrad node per parameter)
-            who = self.names.get(id(self.flat.params[idx]), f"#{idx}")
-            raise RuntimeError(f"parameter {who}: second post-accumulate-grad hook in one backward -- call begin() between backwards")
+        if idx in self._seen:                              # one AccumulateGrad node per parameter: a second hook = a new backward
+            if self.enabled and self.sync and self.overlap and self.handles:
+                who = self.names.get(id(self.flat.params[idx]), f"#{idx}")
+                raise RuntimeError(f"parameter {who}: a new backward started while buckets of the previous one are in flight -- "
+                                   "call finish() (or begin()) between backwards")
+            self._open()
         self._seen.add(idx)
         self.order_log.append(idx)
         if not (self.enabled and self.sync and self.overlap):

@@ -112,7 +112,7 @@ def test_full_size_one_sample_gradient_vs_oracle(full):
         # are exactly zero in exact arithmetic (GlobalContext's to_k.bias: the softmax over L ignores a constant shift)
         floor = 1e-4 * ref_flat.norm().item() / len(gref) ** 0.5
         for mode, tol_loss, tol_flat, tol_norm_max, tol_norm_med in ((torch.float32, 1e-5, 2e-3, 2e-2, 1e-3),
-                                                                     (torch.bfloat16, 2e-2, 6e-2, 2.5e-1, 3e-2)):
+                                                                     (torch.bfloat16, 1e-3, 2e-2, 3e-1, 2e-2)):
             trainer.flat.zero_grad()
             with oa.forced_compute_dtype(mode):
                 loss = model.loss_with(xs.cuda(), as_.cuda(), cs.cuda(), ns.cuda(), ts.cuda(), cond_drop_prob=0.0)

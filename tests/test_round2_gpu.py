@@ -71,6 +71,25 @@ def test_every_attention_backward_kernel_vs_fp32_autograd(N):
         assert relmax(got_r.float(), ref_r.float()) < 8e-3, name
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("Bn,L,H,K", [(2, 200, 2, 96), (3, 64, 1, 40), (4, 4096, 16, 256)])     # 128^2-tile path (ragged M) and the 256^2 path
+def test_gemm_rowdot_epilogue(dtype, tol, Bn, L, H, K):
+    """osuf_gemm_nt_rowdot == osuf_gemm_nt followed by osuf_attn_delta (the to_out input gradient + sum_d dO * O of unet.py:141 /
+    attention.py:94-99's backward), from one epilogue."""
+    a = (torch.randn(Bn * L, K, device=DEV) * 0.5).to(dtype)
+    w = (torch.randn(1, H * 64, K, device=DEV) / K ** 0.5).to(dtype)
+    o = torch.randn(Bn, L, H * 64, device=DEV).to(torch.bfloat16).to(dtype)          # attention outputs hold bf16-rounded values
+    c_ref = ops.gemm_nt(a, w, None)
+    c, delta = ops.gemm_nt_rowdot(a, w, o, L, H)
+    assert torch.equal(c.view_as(c_ref), c_ref)
+    want = (c_ref.to(torch.bfloat16).float().view(Bn, L, H, 64) * o.float().view(Bn, L, H, 64)).sum(-1).permute(0, 2, 1)
+    assert delta.shape == (Bn, H, L) and relmax(delta, want) < 1e-5
+    d2 = torch.empty_like(delta)                                                       # and the stand-alone kernel it replaces
+    ops.call("osuf_attn_delta", c_ref.to(torch.bfloat16).data_ptr(), H * 64, o.data_ptr(), H * 64, ops._DT[o.dtype], d2.data_ptr(), Bn, H, L, 64,
+             torch.cuda.current_stream().cuda_stream)
+    assert relmax(delta, d2) < 1e-5
+
+
 def test_attention_backward_rejects_unknown_variant():
     qkv = torch.zeros(1, 64, 6 * 64, device=DEV, dtype=torch.bfloat16)
     o, lse = ops.mqa_fwd(qkv, 1, 64, 4, 64, torch.bfloat16, 0.125)
@@ -244,11 +263,16 @@ def test_trainer_gradient_accumulation_and_relayout(golden_dir):
         assert tr2.opt.step_count == 1 and abs(n1.item() - n2.item()) < 2e-3 * n1.item()
         assert [id(p) for p in tr2.flat.params] != first_layout, "the completion order differs from reverse registration order"
         g2, m2st = named(tr2, tr2.flat.grad), named(tr2, tr2.opt.exp_avg)
-        gfloor = 1e-5 * max(v.abs().max().item() for v in g1.values())      # some gradients are exactly zero in exact arithmetic
-        mfloor = 1e-5 * max(v.abs().max().item() for v in m1st.values())    # (GlobalContext's to_k.bias): compare above a floor
+        # tolerance: everything outside attention is exact fp32 here, but the reference's bf16 cast of q / k / v (attention.py:87-92)
+        # turns last-bit differences of the projections (B = 4 vs 2 + 2 take different tile / split plans) into isolated 2^-9 jumps:
+        # ~2e-4 rel-L2 run to run (noise floor).  Per parameter the error is taken relative to its largest element
+        # or 1e-3 of the model's largest gradient element, whichever is larger (attention weights carry gradients 1e-4 of the rest)
+        gmax = max(v.abs().max().item() for v in g1.values())
+        mmax = max(v.abs().max().item() for v in m1st.values())
         for k in g1:
-            assert relmax(g2[k] / 2, g1[k]) < 2e-3 or g1[k].abs().max() < gfloor, k    # sum of two half-batch means = 2 x full mean
-            assert relmax(m2st[k], m1st[k]) < 2e-3 or m1st[k].abs().max() < mfloor, k  # Adam moments moved with their parameter
+            assert (g2[k] / 2 - g1[k]).abs().max().item() <= 1e-2 * max(g1[k].abs().max().item(), 1e-3 * gmax), k   # 2 half-batch means = 2 x full mean
+            assert (m2st[k] - m1st[k]).abs().max().item() <= 1e-2 * max(m1st[k].abs().max().item(), 1e-3 * mmax), k  # Adam moments moved along
+        assert rell2(torch.cat([g2[k] / 2 for k in g1]), torch.cat([g1[k] for k in g1])) < 1e-3
         for p, o in zip(tr2.flat.params, tr2.flat.offsets):
             assert p.data_ptr() == tr2.flat.data.data_ptr() + 4 * o and p.grad.data_ptr() == tr2.flat.grad.data_ptr() + 4 * o
         tr2.step(x[:2], a[:2], c[:2], noise[:2], t[:2])

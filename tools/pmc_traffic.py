@@ -1,0 +1,41 @@
+"""HBM-side bytes per launch of the attention kernels from two rocprofv3 --pmc passes over `python bench.py ...` (one with
+FETCH_SIZE, one with WRITE_SIZE; csv output), written to profiles/attn_hbm_traffic.json -- the file bench.py's
+roofline.traffic is read from.  As MI355X_MICROARCH.md "HBM" prescribes for gfx950: FETCH_SIZE / WRITE_SIZE are in KiB, and
+FETCH_SIZE reports half of the bytes of wide (16 B / lane) streaming reads, so it is doubled; WRITE_SIZE is exact.
+
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <source tag> [out.json]
+"""
+import collections
+import csv
+import json
+import sys
+
+ENTRY = {"mqa_fwd_kernel": "osuf_mqa_fwd", "mqa_bwd_fused_kernel": "osuf_mqa_bwd_fused", "mqa_bwd_dq_pipe_kernel": "osuf_mqa_bwd_dq",
+         "mqa_bwd_dq_kernel": "osuf_mqa_bwd_dq", "mqa_bwd_dkv_pipe_kernel": "osuf_mqa_bwd_dkv", "mqa_bwd_dkv_kernel": "osuf_mqa_bwd_dkv"}
+
+
+def per_kernel(path, counter):
+    tot, n = collections.defaultdict(float), collections.defaultdict(int)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        if name in ENTRY:
+            tot[ENTRY[name]] += float(r["Counter_Value"]) * 1024.0
+            n[ENTRY[name]] += 1
+    return tot, n
+
+
+fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
+write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
+tag = sys.argv[3]
+out = {}
+for k in sorted(set(fetch) | set(write)):
+    f = 2.0 * fetch[k] / max(nf[k], 1)
+    w = write[k] / max(nw[k], 1)
+    out[k] = {"bytes_per_launch": round(f + w), "fetch_bytes_x2": round(f), "write_bytes": round(w), "launches_profiled": nf[k],
+              "source": tag}
+    print(f"{k:22s} launches {nf[k]:5d}  fetched (x2) {f / 1e6:9.1f} MB  written {w / 1e6:9.1f} MB  per launch")
+path = sys.argv[4] if len(sys.argv) > 4 else "profiles/attn_hbm_traffic.json"
+json.dump(out, open(path, "w"), indent=1)
+print("wrote", path)
