@@ -226,6 +226,14 @@ def global_context(p: Dict[str, Tensor], pre: str, h: Tensor, nm: Numerics) -> T
     return torch.sigmoid(g)[..., None]
 
 
+def squeeze_excite(p: Dict[str, Tensor], pre: str, h: Tensor, nm: Numerics) -> Tensor:
+    """residual.py:40-59 (the gate ResidualBlock(use_gca=False) builds, residual.py:116): mean over the sequence -> 1x1 MLP -> sigmoid."""
+    pooled = h.mean(dim=-1)                                                        # AdaptiveAvgPool1d(1)
+    g = nm.lin(pooled, p[f"{pre}.layers.0.weight"], p[f"{pre}.layers.0.bias"])
+    g = nm.lin(F.silu(g), p[f"{pre}.layers.2.weight"], p[f"{pre}.layers.2.bias"])
+    return torch.sigmoid(g)[..., None]
+
+
 def block(p, pre, x, scale_shift, nm: Numerics) -> Tensor:
     """residual.py:75-84: conv3 -> GroupNorm(1,C) -> FiLM -> SiLU."""
     y = F.conv1d(x, nm.w(p[f"{pre}.proj.weight"]), p[f"{pre}.proj.bias"], padding=1)
@@ -247,7 +255,7 @@ def residual_block(p, pre, x, t, c, nm: Numerics) -> Tensor:
         scale_shift = emb.chunk(2, dim=1)
     h = block(p, f"{pre}.block1", x, scale_shift, nm)
     h = block(p, f"{pre}.block2", h, None, nm)
-    gate = global_context(p, f"{pre}.se", h, nm)
+    gate = global_context(p, f"{pre}.se", h, nm) if f"{pre}.se.to_k.weight" in p else squeeze_excite(p, f"{pre}.se", h, nm)
     if f"{pre}.res_conv.weight" in p:
         res = F.conv1d(x, nm.w(p[f"{pre}.res_conv.weight"]), p[f"{pre}.res_conv.bias"])
     else:

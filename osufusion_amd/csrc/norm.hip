@@ -540,16 +540,24 @@ __global__ __launch_bounds__(256) void gate_residual_kernel(const T* h, long ldh
 
 // GlobalContext backward, row-wise:
 //   dp = h[m,:].dpooled[b,:] ; dlogit = p[m] * (dp - sdot[b]) ; dh = dout*gate[b] + p[m]*dpooled[b] + dlogit*wk
+// dwk / dbk (optional, accumulated into): the gradients of the pooling logits' weight and bias, sum_m dlogit[m] * h[m][:] and
+// sum_m dlogit[m] -- taken from the h row this kernel already holds in registers (round 1 re-read h in a wcolsum pass and
+// summed dlogit with two torch reductions: 3 launches and one pass over h per block)
 template <typename T>
 __global__ __launch_bounds__(256) void gca_bwd_apply_kernel(const T* dout, long lddo, const T* h, long ldh, T* dh, long lddh,
                                                             const float* p, const float* gate, const float* dpooled,
                                                             const float* sdot, const float* wk, float* dlogit,
-                                                            int M, int C, int L, int G) {
+                                                            int M, int C, int L, int G, float* dwk, float* dbk) {
   const int chunks = C >> 3;
   const int rows_per_wave = 64 / G;
   const int lane = threadIdx.x & 63, gl = lane % G, gr = lane / G;
   const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  float aw[kMaxCh][8], ab = 0.f;
+#pragma unroll
+  for (int j = 0; j < kMaxCh; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) aw[j][e] = 0.f;
   for (long m0 = (long)wave_global * rows_per_wave; m0 < M; m0 += (long)waves_total * rows_per_wave) {
     const long m = m0 + gr;
     const bool rok = m < M;
@@ -571,11 +579,15 @@ __global__ __launch_bounds__(256) void gca_bwd_apply_kernel(const T* dout, long 
     if (rok) {
       const float pm = p[m];
       const float dl = pm * (s - sdot[b]);
-      if (gl == 0) dlogit[m] = dl;
+      if (gl == 0) { dlogit[m] = dl; ab += dl; }
 #pragma unroll
       for (int j = 0; j < kMaxCh; ++j) {
         const int ch = gl + j * G;
         if (ch < chunks) {
+          if (dwk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) aw[j][e] += dl * hv[j][e];
+          }
           float d[8], g[8], dp[8], w[8], o[8];
           load8(dout + m * lddo + ch * 8, d);
           load8(gate + b * C + ch * 8, g);
@@ -587,6 +599,32 @@ __global__ __launch_bounds__(256) void gca_bwd_apply_kernel(const T* dout, long 
         }
       }
     }
+  }
+  if (dwk) {                                               // uniform: rows of a wave (lanes with equal gl) -> waves of the block -> atomics
+    extern __shared__ __attribute__((aligned(16))) char smem_gca[];
+    float* red = reinterpret_cast<float*>(smem_gca);       // [4][C] | [4]
+    for (int off = G; off < 64; off <<= 1) {
+#pragma unroll
+      for (int j = 0; j < kMaxCh; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) aw[j][e] += __shfl_xor(aw[j][e], off, 64);
+      ab += __shfl_xor(ab, off, 64);
+    }
+    const int wv = threadIdx.x >> 6;
+    if (gr == 0) {
+#pragma unroll
+      for (int j = 0; j < kMaxCh; ++j) {
+        const int ch = gl + j * G;
+        if (ch < chunks) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) red[wv * C + ch * 8 + e] = aw[j][e];
+        }
+      }
+      if (gl == 0) red[4 * C + wv] = ab;
+    }
+    __syncthreads();
+    for (int cc = threadIdx.x; cc < C; cc += blockDim.x) atomic_add_f32(dwk + cc, (red[cc] + red[C + cc]) + (red[2 * C + cc] + red[3 * C + cc]));
+    if (threadIdx.x == 0 && dbk) atomic_add_f32(dbk, (red[4 * C] + red[4 * C + 1]) + (red[4 * C + 2] + red[4 * C + 3]));
   }
 }
 
@@ -735,10 +773,13 @@ extern "C" int osuf_gate_residual(int dtype, const void* h, long ldh, const floa
 
 extern "C" int osuf_gca_bwd_apply(int dtype, const void* dout, long lddo, const void* h, long ldh, void* dh, long lddh, const float* p,
                                   const float* gate, const float* dpooled, const float* sdot, const float* wk, float* dlogit,
-                                  int M, int C, int L, hipStream_t stream) {
-  if (bad_c(C) || M <= 0 || L <= 0 || M % L || lddo % 8 || ldh % 8 || lddh % 8) return OSUF_EINVAL;
+                                  int M, int C, int L, float* dwk, float* dbk, hipStream_t stream) {
+  if (bad_c(C) || M <= 0 || L <= 0 || M % L || lddo % 8 || ldh % 8 || lddh % 8 || (dbk && !dwk)) return OSUF_EINVAL;
   const int G = pick_group(C / 8);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(gca_bwd_apply_kernel<T>, dim3(row_grid(M, G)), dim3(256), 0, stream, (const T*)dout, lddo,
-                                       (const T*)h, ldh, (T*)dh, lddh, p, gate, dpooled, sdot, wk, dlogit, M, C, L, G));
+  const size_t lds = dwk ? (size_t)(4 * C + 4) * sizeof(float) : 0;
+  int blocks = row_grid(M, G);
+  if (dwk && blocks > 1024) blocks = 1024;                 // bounds the dwk atomics (C per block)
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gca_bwd_apply_kernel<T>, dim3(blocks), dim3(256), lds, stream, (const T*)dout, lddo,
+                                       (const T*)h, ldh, (T*)dh, lddh, p, gate, dpooled, sdot, wk, dlogit, M, C, L, G, dwk, dbk));
   return osuf_launch_status();
 }

@@ -484,6 +484,7 @@ class GCAPoolFn(torch.autograd.Function):
         pooled = ops.wcolsum(h, None, p, B, L)
         ctx.save_for_backward(h, wkv, p, pooled)
         ctx.wshape, ctx.link = wk.shape, link
+        ctx.wk_ref, ctx.bk_ref = wk, bk                   # the Parameters themselves (direct .grad accumulation)
         return pooled
 
     @staticmethod
@@ -496,17 +497,62 @@ class GCAPoolFn(torch.autograd.Function):
         h, wkv, p, pooled = ctx.saved_tensors
         B, L, C = h.shape
         dpooled = dpooled.contiguous().float()
-        sdot = (pooled * dpooled).sum(1).contiguous()
+        sdot = ops.rowdot(pooled, dpooled, None, 1, per_sample=True)       # sum_c pooled * dpooled per sample, one launch
         link = ctx.link
         if link is not None and link.dout is not None:
             dout, gate = link.dout, link.gate
             link.dout = link.gate = None
         else:                                              # stand-alone GlobalContext: no dout * gate term
             dout, gate = h, torch.zeros((B, C), dtype=torch.float32, device=h.device)
-        dh, dlogit = ops.gca_bwd_apply(dout, h, p, gate, dpooled, sdot, wkv, L)
-        dwk = ops.wcolsum(h, None, dlogit, B, L).sum(0).reshape(ctx.wshape) if ctx.needs_input_grad[1] else None   # frozen base: skip the pass
-        dbk = dlogit.sum().reshape(1) if ctx.needs_input_grad[2] else None
+        # to_k's weight / bias gradients come out of the same kernel (it holds the h rows); straight into .grad under a Trainer
+        need_w, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dwk = dbk = tw = tb = None
+        direct = False
+        if need_w or need_b:                               # (frozen base: neither, the kernel skips the sums)
+            gw, gb = grad_target(ctx.wk_ref), grad_target(ctx.bk_ref)
+            direct = gw is not None and gb is not None
+            if direct:
+                tw, tb = gw.view(-1), gb.view(-1)
+            else:
+                tw = ops.zeros(C, torch.float32, h.device)
+                tb = ops.zeros(1, torch.float32, h.device)
+        dh, dlogit = ops.gca_bwd_apply(dout, h, p, gate, dpooled, sdot, wkv, L, tw, tb)
+        if direct:
+            grad_done(ctx.wk_ref); grad_done(ctx.bk_ref)
+        elif tw is not None:
+            dwk = tw.reshape(ctx.wshape) if need_w else None
+            dbk = tb.reshape(ctx.bk_ref.shape) if need_b else None
         return dh, dwk, dbk, None
+
+
+class MeanPoolFn(torch.autograd.Function):
+    """SqueezeExcite's AdaptiveAvgPool1d(1) (residual.py:42,51): pooled[b, c] = mean_l h[b, l, c] -> fp32 (B, C).  Same hand-off with
+    the gate * h consumer as GCAPoolFn (GateLink); the backward reuses osuf_gca_bwd_apply with uniform weights 1/L and a zero logit
+    weight: dh = dout * gate + dpooled / L."""
+
+    @staticmethod
+    def forward(ctx, h, link=None):
+        B, L, C = h.shape
+        ctx.save_for_backward(h)
+        ctx.link = link
+        return ops.wcolsum(h, None, None, B, L) * (1.0 / L)
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        (h,) = ctx.saved_tensors
+        B, L, C = h.shape
+        dev = h.device
+        dpooled = dpooled.contiguous().float()
+        link = ctx.link
+        if link is not None and link.dout is not None:
+            dout, gate = link.dout, link.gate
+            link.dout = link.gate = None
+        else:
+            dout, gate = h, torch.zeros((B, C), dtype=torch.float32, device=dev)
+        p = torch.full((B * L,), 1.0 / L, dtype=torch.float32, device=dev)
+        dh, _ = ops.gca_bwd_apply(dout, h, p, gate, dpooled, torch.zeros(B, dtype=torch.float32, device=dev),
+                                  torch.zeros(C, dtype=torch.float32, device=dev), L)
+        return dh, None
 
 
 def _gate_dh(link, dout, gate, L):

@@ -42,6 +42,28 @@ class GlobalContext(nn.Module):
         return self.gate_from_rows(h).unsqueeze(-1)
 
 
+class SqueezeExcite(nn.Module):
+    """residual.py:40-59: mean over the sequence -> Conv1d(1x1) -> SiLU -> Conv1d(1x1) -> sigmoid.  forward(x: (B,C,L)) -> (B, C_out, 1).
+    The gate ResidualBlock(use_gca=False) uses (residual.py:116); same state-dict keys (`layers.0`, `layers.2`; the pool has none)."""
+
+    def __init__(self, dim: int, dim_out: int, reduction: int = 2, dim_minimum: int = 8) -> None:
+        super().__init__()
+        inner_dim = max(dim_minimum, dim_out // reduction)
+        self.global_avg_pool = nn.AdaptiveAvgPool1d(1)
+        self.layers = nn.Sequential(nn.Conv1d(dim, inner_dim, 1), nn.SiLU(), nn.Conv1d(inner_dim, dim_out, 1), nn.Sigmoid())
+
+    def gate_from_rows(self, h: torch.Tensor, link=None) -> torch.Tensor:
+        with scope("SqueezeExcite"):                       # residual.py:57
+            pooled = Fn.MeanPoolFn.apply(h, link)
+            l0, l2 = self.layers[0], self.layers[2]
+            z = rt.small_linear(pooled, l0.weight, l0.bias)
+            return rt.small_linear(z, l2.weight, l2.bias, in_act=ops.ACT_SILU, out_act=ops.ACT_SIGMOID)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        h = rt.to_rows(x, rt.compute_dtype(self.layers[0].weight.dtype))
+        return self.gate_from_rows(h).unsqueeze(-1)
+
+
 class Block(nn.Module):
     """residual.py:62-88: Conv1d(k3) -> GroupNorm(1, C) -> FiLM -> SiLU."""
 
@@ -74,8 +96,6 @@ class ResidualBlock(nn.Module):
     def __init__(self, dim_in: int, dim_out: int, dim_time: Optional[int] = None, dim_cond: Optional[int] = None,
                  use_gca: bool = True) -> None:
         super().__init__()
-        if not use_gca:
-            raise NotImplementedError("SqueezeExcite (use_gca=False) is never built by the UNet and has no HIP path")
         self.has_time_cond = dim_time is not None
         self.has_cond = dim_cond is not None
         self.mlp = (
@@ -86,7 +106,7 @@ class ResidualBlock(nn.Module):
         self.block1 = Block(dim_in, dim_out)
         self.block2 = Block(dim_out, dim_out)
         self.res_conv = nn.Conv1d(dim_in, dim_out, 1) if dim_in != dim_out else nn.Identity()
-        self.se = GlobalContext(dim_out, dim_out)
+        self.se = GlobalContext(dim_out, dim_out) if use_gca else SqueezeExcite(dim_out, dim_out)
         self._cr = Fn.PackCache()
 
     def forward_rows(self, x: torch.Tensor, t: Optional[torch.Tensor], c: Optional[torch.Tensor]) -> torch.Tensor:

@@ -345,12 +345,14 @@ def gate_residual(h: torch.Tensor, gate: torch.Tensor, res: Optional[torch.Tenso
     return out
 
 
-def gca_bwd_apply(dout, h, p, gate, dpooled, sdot, wk, L: int):
+def gca_bwd_apply(dout, h, p, gate, dpooled, sdot, wk, L: int, dwk_out: Optional[torch.Tensor] = None,
+                  dbk_out: Optional[torch.Tensor] = None):
+    """dwk_out (C,) / dbk_out (1,) fp32, optional: accumulated into (+= sum_m dlogit[m] h[m][:], += sum_m dlogit[m])."""
     M, C, ld = _rows(h)
     dh = torch.empty(h.shape, dtype=h.dtype, device=h.device)
     dlogit = torch.empty(M, dtype=torch.float32, device=h.device)
     call("osuf_gca_bwd_apply", dt_of(h), _p(dout), _rows(dout)[2], _p(h), ld, _p(dh), C, _p(p), _p(gate), _p(dpooled), _p(sdot), _p(wk),
-         _p(dlogit), M, C, L, _stream())
+         _p(dlogit), M, C, L, _p(dwk_out), _p(dbk_out), _stream())
     return dh, dlogit
 
 

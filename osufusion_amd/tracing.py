@@ -20,7 +20,7 @@ _NOOP = nullcontext()
 _ENABLED = bool(os.environ.get("OSUF_TRACE")) and not os.environ.get("DEBUG")
 _roctx = None
 
-SCOPES = ("Upsample", "Downsample", "Attention", "GlobalContext", "Residual's Block")      # the reference's scope names
+SCOPES = ("Upsample", "Downsample", "Attention", "GlobalContext", "SqueezeExcite", "Residual's Block")      # the reference's scope names
 
 
 def _lib():

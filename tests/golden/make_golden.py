@@ -151,6 +151,19 @@ def module_cases() -> None:
     load_pattern(m)
     save("mod_audio_encoder", y=m(T(uniform_pm("mod/xae", (B, 96, 64), 1.0))))
 
+    # round 2: the squeeze-excite gate (residual.py:40-59) and a ResidualBlock built with use_gca=False (residual.py:116),
+    # with the gradients of its input and of two of its parameters (the reference's autograd)
+    m = ref_residual.SqueezeExcite(48, 48)
+    load_pattern(m)
+    save("mod_squeeze_excite", y=m(x))
+    m = ref_residual.ResidualBlock(48, 80, 64, 64, use_gca=False)
+    load_pattern(m)
+    xg = x.clone().requires_grad_()
+    y = m(xg, t, c)
+    gy = T(uniform_pm("mod/gy_se", tuple(y.shape), 1.0))
+    y.backward(gy)
+    save("mod_resblock_se", y=y, dx=xg.grad, dw_se0=m.se.layers[0].weight.grad, dw_proj1=m.block1.proj.weight.grad)
+
 
 # --------------------------------------------------------------------------------------
 # UNet-level cases

@@ -407,6 +407,16 @@ def test_modules_vs_golden(golden_dir):
         assert relmax(m(x, t, c), G(golden_dir, "mod_resblock_film")["y"]) < TOL
         m = load_pattern(R.ResidualBlock(48, 48, None, None).to(DEV))
         assert relmax(m(x), G(golden_dir, "mod_resblock_plain")["y"]) < TOL
+        m = load_pattern(R.SqueezeExcite(48, 48).to(DEV))                     # the use_gca=False gate (residual.py:40-59,116)
+        assert relmax(m(x), G(golden_dir, "mod_squeeze_excite")["y"]) < TOL
+        m = load_pattern(R.ResidualBlock(48, 80, 64, 64, use_gca=False).to(DEV))
+        g = G(golden_dir, "mod_resblock_se")
+        xg = x.clone().requires_grad_()
+        y = m(xg, t, c)
+        assert relmax(y, g["y"]) < TOL
+        y.backward(T(uniform_pm("mod/gy_se", tuple(y.shape), 1.0)))
+        assert relmax(xg.grad, g["dx"]) < TOL and relmax(m.se.layers[0].weight.grad, g["dw_se0"]) < TOL
+        assert relmax(m.block1.proj.weight.grad, g["dw_proj1"]) < TOL
         m = load_pattern(U.Downsample(48, 80).to(DEV))
         assert relmax(m(x), G(golden_dir, "mod_downsample")["y"]) < TOL
         m = load_pattern(U.Upsample(48, 80).to(DEV))

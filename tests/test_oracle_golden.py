@@ -57,6 +57,20 @@ def test_block_and_residual(golden_dir):
            ("layers.2.weight", (48, 24, 1)), ("layers.2.bias", (48,))])
     close(O.global_context(p, "m", x, NM), G(golden_dir, "mod_global_context")["y"])
 
+    # squeeze-excite gate and a ResidualBlock(use_gca=False), with the reference's own gradients (round 2 fixtures)
+    p = P([("layers.0.weight", (24, 48, 1)), ("layers.0.bias", (24,)), ("layers.2.weight", (48, 24, 1)), ("layers.2.bias", (48,))])
+    close(O.squeeze_excite(p, "m", x, NM), G(golden_dir, "mod_squeeze_excite")["y"])
+    shapes = [(k, v) for k, v in strip(O._resblock_shapes("m", 48, 80, 128), "m") if "se.to_k" not in k]
+    p = {k: v.clone().requires_grad_() for k, v in P(shapes).items()}
+    xg = x.clone().requires_grad_()
+    g = G(golden_dir, "mod_resblock_se")
+    y = O.residual_block(p, "m", xg, t, c, NM)
+    close(y, g["y"])
+    y.backward(T(uniform_pm("mod/gy_se", tuple(y.shape), 1.0)))
+    close(xg.grad, g["dx"], tol=2e-4)
+    close(p["m.se.layers.0.weight"].grad, g["dw_se0"], tol=2e-4)
+    close(p["m.block1.proj.weight"].grad, g["dw_proj1"], tol=2e-4)
+
 
 def test_samplers_and_stems(golden_dir):
     x = T(uniform_pm("mod/x48", (B, 48, 96), 1.0))
