@@ -86,7 +86,9 @@ int osuf_gn_apply_fwd(int dtype, const void* y, long ldy, void* h, long ldh, con
                       const float* beta, const float* scale_shift, int M, int C, int L, hipStream_t stream);
 /* T1234 [B][4][C] fp32 zeroed scratch; S [B][2] scratch; dss [B][2C] (may be NULL); dgamma/dbeta accumulated into; dbias (may be
  * NULL): gradient of the bias of the conv that produced y (= column sums of dy, residual.py:77 `self.proj`), accumulated into;
- * dyy (may be NULL, needs dbias): column sums of dy*y -- the DoRA magnitude gradient's numerator (lora_layers.py:86-90) */
+ * dyy (may be NULL, needs dbias): column sums of dy*y -- the DoRA magnitude gradient's numerator (lora_layers.py:86-90).
+ * dgamma == dbeta == NULL: the identity "norm" of Block(norm=False) (residual.py:71): the caller passes mean 0 / rstd 1 / gamma 1 /
+ * beta 0 and the kernels drop every statistics term (dy = (1 + scale) * dh * silu'(u)). */
 int osuf_gn_bwd(int dtype, const void* dh, long lddh, const void* y, long ldy, void* dy, long lddy, const float* mean_rstd,
                 const float* gamma, const float* beta, const float* scale_shift, float* T1234, float* S, float* dss,
                 float* dgamma, float* dbeta, float* dbias, float* dyy, int M, int C, int L, hipStream_t stream);

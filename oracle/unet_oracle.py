@@ -235,10 +235,12 @@ def squeeze_excite(p: Dict[str, Tensor], pre: str, h: Tensor, nm: Numerics) -> T
 
 
 def block(p, pre, x, scale_shift, nm: Numerics) -> Tensor:
-    """residual.py:75-84: conv3 -> GroupNorm(1,C) -> FiLM -> SiLU."""
+    """residual.py:75-84: conv3 -> GroupNorm(1,C) -> FiLM -> SiLU.  Without `norm.*` parameters: Block(norm=False), whose norm is
+    nn.Identity (residual.py:71)."""
     y = F.conv1d(x, nm.w(p[f"{pre}.proj.weight"]), p[f"{pre}.proj.bias"], padding=1)
     y = nm.act(y)                                                      # HIP path: conv output stored, stats on stored values
-    y = F.group_norm(y, 1, p[f"{pre}.norm.weight"], p[f"{pre}.norm.bias"], eps=1e-5)
+    if f"{pre}.norm.weight" in p:
+        y = F.group_norm(y, 1, p[f"{pre}.norm.weight"], p[f"{pre}.norm.bias"], eps=1e-5)
     if scale_shift is not None:
         scale, shift = scale_shift
         y = y * (scale + 1) + shift

@@ -195,15 +195,19 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* T12, 
     s1 += g * k * t2;
     s2 += g * k * t1;
     if (dss) { dss[(long)b * 2 * C + c] = g * t1 + bt * t2; dss[(long)b * 2 * C + C + c] = t2; }
-    atomic_add_f32(dgamma + c, k * t1);
-    atomic_add_f32(dbeta + c, k * t2);
+    if (dgamma) {
+      atomic_add_f32(dgamma + c, k * t1);
+      atomic_add_f32(dbeta + c, k * t2);
+    }
   }
   __shared__ float r1[4], r2[4];
   s1 = group_sum<64>(s1);
   s2 = group_sum<64>(s2);
   if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
   __syncthreads();
-  const float S1 = r1[0] + r1[1] + r1[2] + r1[3], S2 = r2[0] + r2[1] + r2[2] + r2[3];
+  // dgamma == NULL: y was not normalised at all (Block(norm=False), residual.py:71; the caller passes mean 0, rstd 1, gamma 1, beta 0):
+  // no statistics, hence none of their gradient terms
+  const float S1 = dgamma ? r1[0] + r1[1] + r1[2] + r1[3] : 0.f, S2 = dgamma ? r2[0] + r2[1] + r2[2] + r2[3] : 0.f;
   if (threadIdx.x == 0) { S[2 * b] = S1; S[2 * b + 1] = S2; }
   if (dbias) {
     const float mean = mr[2 * b], rstd = mr[2 * b + 1];
@@ -697,7 +701,7 @@ extern "C" int osuf_gn_bwd(int dtype, const void* dh, long lddh, const void* y, 
   const int chunks = C / 8;
   const int rp = 256 / chunks;
   const int rows_per_block = 64;
-  if (dyy && !dbias) return OSUF_EINVAL;
+  if ((dyy && !dbias) || ((dgamma == nullptr) != (dbeta == nullptr))) return OSUF_EINVAL;
   const size_t lds = (size_t)4 * rp * C * sizeof(float);
   const float inv_count = 1.0f / ((float)L * (float)C);
   DISPATCH_T(dtype, hipLaunchKernelGGL(gn_bwd_reduce_kernel<T>, dim3((L + rows_per_block - 1) / rows_per_block, B), dim3(256), lds,

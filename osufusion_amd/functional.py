@@ -375,22 +375,40 @@ class SkinnyLinearFn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+_UNIT_NORM: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def _unit_norm(C: int, device):
+    """(ones(C), zeros(C)) standing for gamma / beta of the identity norm of Block(norm=False)."""
+    key = (C, str(device))
+    if key not in _UNIT_NORM:
+        _UNIT_NORM[key] = (torch.ones(C, dtype=torch.float32, device=device), torch.zeros(C, dtype=torch.float32, device=device))
+    return _UNIT_NORM[key]
+
+
 class BlockFn(torch.autograd.Function):
     """conv k3 -> GroupNorm(1,C) -> FiLM -> SiLU   (residual.py:75-84).  ss: fp32 (B, 2C) = (scale | shift) or None.
+    gamma / beta None: Block(norm=False) (residual.py:71, nn.Identity instead of the GroupNorm) -- the same kernels with mean 0, rstd 1.
     adapter (+ its parameters la, lb, lm as autograd inputs): LoRA / DoRA on the conv (block{1,2}.proj, trainer_peft.py:241)."""
 
     @staticmethod
     def forward(ctx, x, w, bias, gamma, beta, ss, cache, adapter=None, la=None, lb=None, lm=None, reslink=None):
         B, L, _ = x.shape
         C = w.shape[0]
-        repro = ops.reproducible()                         # sampler: statistics by fixed-order reductions, not epilogue atomics
+        ctx.identity_norm = gamma is None
+        if ctx.identity_norm:
+            gamma, beta = _unit_norm(C, x.device)
+        repro = ops.reproducible() or ctx.identity_norm   # sampler: statistics by fixed-order reductions, not epilogue atomics
         stats = None if repro else ops.zeros((B, 2), torch.float64, x.device)
         if adapter is not None:
             weff, _ = adapter.effective()
             y = conv_forward(x, weff, bias, cache, "same", ("dora", *adapter.params), stats=stats)
         else:
             y = conv_forward(x, w, bias, cache, "same", None, stats=stats)
-        mr = ops.gn_stats(y, L) if repro else ops.gn_finalize(stats, L * C)
+        if ctx.identity_norm:
+            mr = torch.tensor([0.0, 1.0], dtype=torch.float32, device=x.device).repeat(B, 1)
+        else:
+            mr = ops.gn_stats(y, L) if repro else ops.gn_finalize(stats, L * C)
         ssc = ss.contiguous() if ss is not None else None
         h = ops.gn_apply(y, mr, gamma, beta, ssc, L)
         ctx.save_for_backward(x, w, y, mr, gamma, beta, ssc if ssc is not None else mr)
@@ -409,7 +427,7 @@ class BlockFn(torch.autograd.Function):
         ss = ss if ctx.has_ss else None
         L = x.shape[1]
         need = ctx.needs_input_grad
-        tg, tb = grad_target(gamma), grad_target(beta)
+        tg, tb = (None, None) if ctx.identity_norm else (grad_target(gamma), grad_target(beta))
         direct_norm = tg is not None and tb is not None
         # conv-bias gradient (= column sums of dy) comes out of the GroupNorm backward in closed form: no extra pass over dy
         bias = ctx.bias_ref
@@ -425,7 +443,7 @@ class BlockFn(torch.autograd.Function):
             dyy = torch.zeros(y.shape[-1], dtype=torch.float32, device=dh.device)
             sdy = tbias if db is not None else torch.zeros(y.shape[-1], dtype=torch.float32, device=dh.device)
         dy, dgamma, dbeta, dss = ops.gn_bwd(_rc(dh), y, mr, gamma, beta, ss, L, tg if direct_norm else None, tb if direct_norm else None,
-                                            sdy if want_dm else tbias, dyy)
+                                            sdy if want_dm else tbias, dyy, identity_norm=ctx.identity_norm)
         if tbias is not None and db is None:
             if want_dm:
                 tbias.add_(sdy)

@@ -69,17 +69,16 @@ class Block(nn.Module):
 
     def __init__(self, dim_in: int, dim_out: int, norm: bool = True) -> None:
         super().__init__()
-        if not norm:
-            raise NotImplementedError("Block(norm=False) is never built by the UNet and has no HIP path")
         self.proj = nn.Conv1d(dim_in, dim_out, 3, padding=1)
-        self.norm = nn.GroupNorm(1, dim_out)
+        self.norm = nn.GroupNorm(1, dim_out) if norm else nn.Identity()
         self.activation = nn.SiLU()
         self._cache = Fn.PackCache()
 
     def forward_rows(self, x: torch.Tensor, ss: Optional[torch.Tensor], reslink=None) -> torch.Tensor:
         extra = self.proj.adapter_inputs() if hasattr(self.proj, "adapter_inputs") else (None, None, None, None)  # lora_layers.LoraConv1d
         with scope("Residual's Block"):                    # residual.py:86
-            return Fn.BlockFn.apply(x, self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias, ss, self._cache, *extra, reslink)
+            gamma, beta = (self.norm.weight, self.norm.bias) if isinstance(self.norm, nn.GroupNorm) else (None, None)
+            return Fn.BlockFn.apply(x, self.proj.weight, self.proj.bias, gamma, beta, ss, self._cache, *extra, reslink)
 
     def forward(self, x: torch.Tensor, scale_shift: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
         rows = rt.to_rows(x, rt.compute_dtype(self.proj.weight.dtype))

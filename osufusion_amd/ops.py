@@ -275,7 +275,7 @@ def gn_apply(y: torch.Tensor, mr: torch.Tensor, gamma: torch.Tensor, beta: torch
 
 def gn_bwd(dh: torch.Tensor, y: torch.Tensor, mr: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ss: Optional[torch.Tensor], L: int,
            dgamma_out: Optional[torch.Tensor] = None, dbeta_out: Optional[torch.Tensor] = None, dbias_out: Optional[torch.Tensor] = None,
-           dyy_out: Optional[torch.Tensor] = None):
+           dyy_out: Optional[torch.Tensor] = None, identity_norm: bool = False):
     """dgamma_out / dbeta_out (fp32 (C,)) are accumulated into when given (parameter .grad buffers); dbias_out (fp32 (C,)) receives
     (+=) the gradient of the bias of the conv that produced y, in closed form from the per-(b, c) sums (no pass over dy); dyy_out
     (fp32 (C,), needs dbias_out) likewise the column sums of dy * y (DoRA magnitude gradient)."""
@@ -286,7 +286,9 @@ def gn_bwd(dh: torch.Tensor, y: torch.Tensor, mr: torch.Tensor, gamma: torch.Ten
     T12 = zeros((B, 4, C), torch.float32, dev)
     S = torch.empty((B, 2), dtype=torch.float32, device=dev)
     dss = torch.empty((B, 2 * C), dtype=torch.float32, device=dev) if ss is not None else None
-    if dgamma_out is None or dbeta_out is None:
+    if identity_norm:                                      # Block(norm=False): no statistics, no gamma / beta
+        dgamma_out = dbeta_out = None
+    elif dgamma_out is None or dbeta_out is None:
         dgb = zeros((2, C), torch.float32, dev)
         dgamma_out, dbeta_out = dgb[0], dgb[1]
     call("osuf_gn_bwd", dt_of(y), _p(dh), _rows(dh)[2], _p(y), ldy, _p(dy), C, _p(mr), _p(gamma), _p(beta), _p(ss), _p(T12), _p(S),

@@ -163,6 +163,14 @@ def module_cases() -> None:
     gy = T(uniform_pm("mod/gy_se", tuple(y.shape), 1.0))
     y.backward(gy)
     save("mod_resblock_se", y=y, dx=xg.grad, dw_se0=m.se.layers[0].weight.grad, dw_proj1=m.block1.proj.weight.grad)
+    # Block(norm=False): nn.Identity in place of the GroupNorm (residual.py:71), with FiLM, and its gradients
+    m = ref_residual.Block(48, 80, norm=False)
+    load_pattern(m)
+    xg = x.clone().requires_grad_()
+    ssg = tuple(v.clone().requires_grad_() for v in ss)
+    y = m(xg, scale_shift=ssg)
+    y.backward(T(uniform_pm("mod/gy_nonorm", tuple(y.shape), 1.0)))
+    save("mod_block_nonorm", y_plain=m(x), y_film=y, dx=xg.grad, dw=m.proj.weight.grad, db=m.proj.bias.grad, dscale=ssg[0].grad, dshift=ssg[1].grad)
 
 
 # --------------------------------------------------------------------------------------

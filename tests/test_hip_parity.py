@@ -407,6 +407,16 @@ def test_modules_vs_golden(golden_dir):
         assert relmax(m(x, t, c), G(golden_dir, "mod_resblock_film")["y"]) < TOL
         m = load_pattern(R.ResidualBlock(48, 48, None, None).to(DEV))
         assert relmax(m(x), G(golden_dir, "mod_resblock_plain")["y"]) < TOL
+        m = load_pattern(R.Block(48, 80, norm=False).to(DEV))                 # nn.Identity instead of the GroupNorm (residual.py:71)
+        g = G(golden_dir, "mod_block_nonorm")
+        xg = x.clone().requires_grad_()
+        ssg = tuple(v.clone().requires_grad_() for v in ss)
+        assert relmax(m(x), g["y_plain"]) < TOL
+        y = m(xg, scale_shift=ssg)
+        assert relmax(y, g["y_film"]) < TOL
+        y.backward(T(uniform_pm("mod/gy_nonorm", tuple(y.shape), 1.0)))
+        for got, key in ((xg.grad, "dx"), (m.proj.weight.grad, "dw"), (m.proj.bias.grad, "db"), (ssg[0].grad, "dscale"), (ssg[1].grad, "dshift")):
+            assert relmax(got, g[key]) < TOL, key
         m = load_pattern(R.SqueezeExcite(48, 48).to(DEV))                     # the use_gca=False gate (residual.py:40-59,116)
         assert relmax(m(x), G(golden_dir, "mod_squeeze_excite")["y"]) < TOL
         m = load_pattern(R.ResidualBlock(48, 80, 64, 64, use_gca=False).to(DEV))

@@ -71,6 +71,18 @@ def test_block_and_residual(golden_dir):
     close(p["m.se.layers.0.weight"].grad, g["dw_se0"], tol=2e-4)
     close(p["m.block1.proj.weight"].grad, g["dw_proj1"], tol=2e-4)
 
+    # Block(norm=False): identity instead of the GroupNorm
+    g = G(golden_dir, "mod_block_nonorm")
+    p = {k: v.clone().requires_grad_() for k, v in P([("proj.weight", (80, 48, 3)), ("proj.bias", (80,))], "m.").items()}
+    xg = x.clone().requires_grad_()
+    ssg = tuple(v.clone().requires_grad_() for v in ss)
+    close(O.block(p, "m", x, None, NM), g["y_plain"])
+    y = O.block(p, "m", xg, ssg, NM)
+    close(y, g["y_film"])
+    y.backward(T(uniform_pm("mod/gy_nonorm", tuple(y.shape), 1.0)))
+    for got, key in ((xg.grad, "dx"), (p["m.proj.weight"].grad, "dw"), (p["m.proj.bias"].grad, "db"), (ssg[0].grad, "dscale"), (ssg[1].grad, "dshift")):
+        close(got, g[key], tol=2e-4)
+
 
 def test_samplers_and_stems(golden_dir):
     x = T(uniform_pm("mod/x48", (B, 48, 96), 1.0))
