@@ -854,7 +854,10 @@ __device__ __forceinline__ int ds_img_off(int key, int qchunk) {     // 8-byte c
 // with plain 8 / 16-byte stores (5x the atomic byte rate, MI355X_MICROARCH "Global float atomics") and dq_reduce_kernel adds the
 // slabs in key-block order -- deterministic, and the sweep is compute-bound again.  bf16 slabs round each 256-key partial once
 // (relative 2^-9, the rounding the bf16 dq output gets anyway); fp32 slabs serve the fp32 compute mode.
-template <int DQ_MODE>
+// RAGGED = N is not a multiple of 32.  Whole-block shapes (every UNet level) take the lean form: no row clamps / selects, and
+// every global address of the loop is a wave-uniform 64-bit base (SGPRs, advanced by scalar adds) plus a loop-invariant 32-bit
+// lane offset -- the clamped per-lane 64-bit form cost ~50 of the loop's 134 VALU instructions.
+template <int DQ_MODE, bool RAGGED>
 __global__ __launch_bounds__(512) void mqa_bwd_fused_kernel(AttnArgs a, float* dq32) {
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][Q 4K | dO 4K | lse 128 | delta 128] | K image 32K | [2] dS image 16K
   constexpr int NW = 8, kStage = 4096 + 4096 + 256;
@@ -903,28 +906,38 @@ __global__ __launch_bounds__(512) void mqa_bwd_fused_kernel(AttnArgs a, float* d
   // the value zeroed by a select afterwards) and loads are issued BEFORE the atomics of the same iteration: waiting for them is
   // then a counted vmcnt(4) that leaves the four younger atomics in flight.
   const int lt = tid & 255, lrow = lt >> 3, lchunk = lt & 7;
-  const bf16_t* lsrc = tid < 256 ? a.q : a.dout;
-  const long lld = tid < 256 ? a.ldq : a.lddo;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);        // scalar copy: selects below stay in SGPRs
+  const bf16_t* lsrc = wave_u < 4 ? a.q : a.dout;                 // waves 0-3 stage the Q tile, 4-7 the dO tile
+  const long lld = wave_u < 4 ? a.ldq : a.lddo;
   const int lds_dst = (tid < 256 ? 0 : 4096) + tile_off(lrow, lchunk * 16);
-  const float* ssrc = (tid & 32) ? a.delta : a.lse2;              // lanes 0-31 of each wave: lse, 32-63: delta (only wave 0 stores them)
-  const float sfill = (tid & 32) ? 0.f : INFINITY;
+  const float* ssrc = (RAGGED ? (tid & 32) != 0 : (wave_u & 1) != 0) ? a.delta : a.lse2;   // ragged: lanes 0-31 lse, 32-63 delta of wave 0;
+  const float sfill = (tid & 32) ? 0.f : INFINITY;                                         // lean: wave 0 lse, wave 1 delta
+  const unsigned loff = (unsigned)(lrow * (int)lld + lchunk * 8);   // (whole-block form) element offset of this lane's chunk in the tile
   const int last_pb = qb_end - 1;
   u32x4 rt; float rs = 0.f;
   int ih = 0, ipb = qb_begin;                                     // (head, query block) of the next stage to load
   auto load_stage = [&]() {
     const int pbc = min(ipb, last_pb);                             // past the end: reload the last block (never consumed)
-    const int qrow = pbc * 32 + lrow, qr = pbc * 32 + (tid & 31);
-    const u32x4 v = *reinterpret_cast<const u32x4*>(lsrc + ((long)b * a.N + min(qrow, a.N - 1)) * lld + ih * D + lchunk * 8);
-    const float sv = ssrc[((long)b * a.H + ih) * a.N + min(qr, a.N - 1)];
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    rt = qrow < a.N ? v : z;
-    rs = qr < a.N ? sv : sfill;
+    if constexpr (RAGGED) {
+      const int qrow = pbc * 32 + lrow, qr = pbc * 32 + (tid & 31);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(lsrc + ((long)b * a.N + min(qrow, a.N - 1)) * lld + ih * D + lchunk * 8);
+      const float sv = ssrc[((long)b * a.H + ih) * a.N + min(qr, a.N - 1)];
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      rt = qrow < a.N ? v : z;
+      rs = qr < a.N ? sv : sfill;
+    } else {
+      const bf16_t* tb = lsrc + ((long)b * a.N + pbc * 32) * lld + ih * D;           // scalar
+      const float* sb = ssrc + ((long)b * a.H + ih) * a.N + pbc * 32;               // scalar
+      rt = *reinterpret_cast<const u32x4*>(tb + loff);
+      rs = sb[(unsigned)(tid & 31)];
+    }
     if (++ih == a.H) { ih = 0; ++ipb; }
   };
   auto store_stage = [&](int slot) {
     char* base = smem + slot * kStage;
     *reinterpret_cast<u32x4*>(base + lds_dst) = rt;
-    if (tid < 64) reinterpret_cast<float*>(base + 8192)[tid] = rs;
+    if constexpr (RAGGED) { if (tid < 64) reinterpret_cast<float*>(base + 8192)[tid] = rs; }
+    else { if (tid < 128 && !(tid & 32)) reinterpret_cast<float*>(base + 8192)[(tid >> 6) * 32 + (tid & 31)] = rs; }
   };
 
   // dQ tile of this wave: queries qh*16 .. +15, head-dim columns dq4*16 .. +15 of the pair handled one iteration earlier
@@ -935,8 +948,10 @@ __global__ __launch_bounds__(512) void mqa_bwd_fused_kernel(AttnArgs a, float* d
   // them every iteration was half of the dQ phase's LDS traffic, 8 KiB per wave and iteration).
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   s16x8 kcol[8];
+  // (whole-block form) element offset of this lane's first dQ value from the (query block, head) base; rows r = 1..3 follow H*64 apart
+  const unsigned aoff = (unsigned)((qh * 16 + 4 * g4) * (a.H * D) + dq4 * 16 + ip);
   auto dq_tile = [&](const char* eb, int ph, int ppb) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // two chains: a single one waits out each MFMA's latency 8 times
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       // k-step ks covers keys 32*ks .. +31: rows 32*ks + 8*g4 + {0..7} of the dS image, whose swizzle (row ^ row >> 3) & 7 changes with
@@ -946,10 +961,13 @@ __global__ __launch_bounds__(512) void mqa_bwd_fused_kernel(AttnArgs a, float* d
       const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(eb + ds_img_off(r0 + 4, qh * 4 + tp)));
       const s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
       const s16x8 bv = kcol[ks];
+      f32x4& c4 = (ks & 1) ? acc1 : acc;
       // atomics: dQ tile (row = query); slabs: dQ^T tile (row = d), so that a lane ends up with 4 consecutive d of one query row
-      if constexpr (DQ_MODE == 0) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
-      else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, av), acc, 0, 0, 0);
+      if constexpr (DQ_MODE == 0) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c4, 0, 0, 0);
+      else c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, av), c4, 0, 0, 0);
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += acc1[r];
     if constexpr (DQ_MODE != 0) {
       // accumulator: column n = lane & 15 -> query, row m = 4 * (lane >> 4) + r -> d.  Slab rows are padded to whole 32-query
       // blocks, so no store is masked (a branch around it would cost the counted waits, see the stage loader)
@@ -961,13 +979,19 @@ __global__ __launch_bounds__(512) void mqa_bwd_fused_kernel(AttnArgs a, float* d
       return;
     }
     // accumulator: column n = lane & 15 -> d, row m = 4 * (lane >> 4) + r -> query
-    // (no branch around the atomics, see the stage loader: a padded query row adds 0.0 to the sample's last row instead)
-    const int qrow0 = ppb * 32 + qh * 16 + 4 * g4;
-    float* dst = dq32 + (long)b * a.N * (a.H * D) + ph * D + dq4 * 16 + ip;
+    if constexpr (RAGGED) {
+      // (no branch around the atomics, see the stage loader: a padded query row adds 0.0 to the sample's last row instead)
+      const int qrow0 = ppb * 32 + qh * 16 + 4 * g4;
+      float* dst = dq32 + (long)b * a.N * (a.H * D) + ph * D + dq4 * 16 + ip;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool ok = qrow0 + r < a.N;
-      atomic_add_f32(dst + (long)min(qrow0 + r, a.N - 1) * (a.H * D), ok ? acc[r] : 0.f);
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = qrow0 + r < a.N;
+        atomic_add_f32(dst + (long)min(qrow0 + r, a.N - 1) * (a.H * D), ok ? acc[r] : 0.f);
+      }
+    } else {
+      float* sb = dq32 + ((long)b * a.N + ppb * 32) * (a.H * D) + ph * D;             // scalar
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomic_add_f32(sb + (aoff + (unsigned)(r * (a.H * D))), acc[r]);
     }
   };
 
@@ -1398,21 +1422,24 @@ extern "C" int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long l
   a.qsplit = dkv_qsplit(B, N, qsplit);
   if (a.qsplit > 1) { a.wsk = wsp; a.wsv = wsp + (long)a.qsplit * B * N * D; }
   const int lds = 2 * (4096 + 4096 + 256) + 32768 + 2 * 16384;
-  static bool once = ((void)hipFuncSetAttribute((const void*)mqa_bwd_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-                      (void)hipFuncSetAttribute((const void*)mqa_bwd_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-                      (void)hipFuncSetAttribute((const void*)mqa_bwd_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), true);
-  (void)once;
+  const bool ragged = (N % 32) != 0;
+  const int mode = dq_mode == OSUF_DQ_ATOMIC ? 0 : (a.g_bf16 ? 1 : 2);
+  void (*kern)(AttnArgs, float*) =
+      mode == 0 ? (ragged ? mqa_bwd_fused_kernel<0, true> : mqa_bwd_fused_kernel<0, false>)
+    : mode == 1 ? (ragged ? mqa_bwd_fused_kernel<1, true> : mqa_bwd_fused_kernel<1, false>)
+                : (ragged ? mqa_bwd_fused_kernel<2, true> : mqa_bwd_fused_kernel<2, false>);
+  static bool attr_set[6] = {false, false, false, false, false, false};
+  if (!attr_set[2 * mode + ragged]) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set[2 * mode + ragged] = true;
+  }
   const int b8 = (B + 7) / 8 * 8;
   const dim3 grid(((N + 255) / 256) * b8 * a.qsplit);
   if (dq_mode == OSUF_DQ_ATOMIC) {
     hipError_t e = hipMemsetAsync(dq32, 0, (size_t)dq_bytes, stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(mqa_bwd_fused_kernel<0>, grid, dim3(512), lds, stream, a, dq32);
-  } else if (a.g_bf16) {
-    hipLaunchKernelGGL(mqa_bwd_fused_kernel<1>, grid, dim3(512), lds, stream, a, dq32);
-  } else {
-    hipLaunchKernelGGL(mqa_bwd_fused_kernel<2>, grid, dim3(512), lds, stream, a, dq32);
   }
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a, dq32);
   if (a.qsplit > 1) {
     const unsigned fb = (unsigned)((M * 32 + 255) / 256);
     if (a.g_bf16) hipLaunchKernelGGL(dkv_finish_kernel<bf16_t>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (bf16_t*)dk, (bf16_t*)dv, lddk, M, N, scale, rope_cos, rope_sin);
