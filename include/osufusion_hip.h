@@ -189,6 +189,23 @@ int osuf_cast_f32_bf16(const float* src, void* dst, long n, hipStream_t stream);
 int osuf_pack_weight(const float* w, int O, int I, int k, int out_dtype, void* F, long f_ld, long f_tapstride, void* D, long d_ld,
                      long d_tapstride, int dkind, hipStream_t stream);
 
+/* The same pack for MANY weights in one launch (after an optimizer step every packed operand of the model is stale at once).
+ * descs: DEVICE array of n descriptors, one per weight, fields as osuf_pack_weight's arguments; block0 = running sum of
+ * ceil(O/32) * ceil(I/32) over the preceding descriptors (descs[0].block0 == 0), total_blocks = that sum over all n.
+ * All destinations share out_dtype.  The table is only read: it can be built once and reused while the pointers stay put. */
+#ifndef OSUF_PACK_DESC_DEFINED
+#define OSUF_PACK_DESC_DEFINED
+typedef struct osuf_pack_desc {
+  const float* w;
+  void* F;
+  void* D;
+  long f_ld, f_tapstride, d_ld, d_tapstride;
+  int O, I, k, dkind;
+  int block0, reserved;
+} osuf_pack_desc;                                   /* 80 bytes */
+#endif
+int osuf_pack_weight_group(const osuf_pack_desc* descs, int n, int total_blocks, int out_dtype, hipStream_t stream);
+
 /* LoRA / DoRA adapters folded into an effective weight (reference: osu_fusion/modules/lora_layers.py:16-26 get_weight_norm,
  * :72-92 DoraConv1dLayer.forward, :284-298 get_delta_weight; peft 0.12 DoraLinearLayer for attn.to_q / attn.to_kv as wired at
  * trainer_peft.py:236-244).  W (O, IK) fp32 frozen base, A (r, IK), B (O, r), mag (O) or NULL for plain LoRA, IK = in*k:

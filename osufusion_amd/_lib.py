@@ -57,6 +57,7 @@ SIGNATURES = {
     "osuf_clip_coef": [P, F, F, P, P, P],
     "osuf_cast_f32_bf16": [P, P, L, P],
     "osuf_pack_weight": [P, I, I, I, I, P, L, L, P, L, L, I, P],
+    "osuf_pack_weight_group": [P, I, I, I, P],
     "osuf_dora_effective": [P, P, P, P, I, I, I, F, P, P, P],
     "osuf_dora_gain": [P, P, P, P, I, I, I, I, F, P, P, P, P, P],
     "osuf_adapter_finish": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],

@@ -3,6 +3,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// descriptor of osuf_pack_weight_group (include/osufusion_hip.h holds the same definition for callers)
+#ifndef OSUF_PACK_DESC_DEFINED
+#define OSUF_PACK_DESC_DEFINED
+typedef struct osuf_pack_desc {
+  const float* w;
+  void* F;
+  void* D;
+  long f_ld, f_tapstride, d_ld, d_tapstride;
+  int O, I, k, dkind;
+  int block0, reserved;
+} osuf_pack_desc;
+#endif
+static_assert(sizeof(osuf_pack_desc) == 80, "osuf_pack_desc is part of the C ABI");
+
 #define OSUF_DT_F32 0
 #define OSUF_DT_BF16 1
 // kernel choice of the attention-backward entry points (per call; nothing is read from the environment)

@@ -318,12 +318,9 @@ __device__ __forceinline__ float adapted_value(const AdaptArgs& ad, const float*
 }
 
 template <typename TO, bool ADAPT>
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int O, int I, int k, TO* F, long f_ld, long f_ts, TO* D,
-                                                          long d_ld, long d_ts, int dkind, AdaptArgs ad) {
-  __shared__ float tile[4][32][33];
-  extern __shared__ float adapt_lds[];                      // ADAPT: As | Bs | gs
+__device__ __forceinline__ void pack_tile(const float* __restrict__ w, int O, int I, int k, TO* F, long f_ld, long f_ts, TO* D, long d_ld, long d_ts,
+                                          int dkind, const AdaptArgs& ad, int o0, int i0, float (*tile)[32][33], float* adapt_lds) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-  const int o0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
   float* As = adapt_lds;
   float* Bs = As + (ADAPT ? ad.r * 32 * k : 0);
   float* gs = Bs + (ADAPT ? 32 * ad.r : 0);
@@ -366,6 +363,35 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
   }
 }
 
+template <typename TO, bool ADAPT>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int O, int I, int k, TO* F, long f_ld, long f_ts, TO* D,
+                                                          long d_ld, long d_ts, int dkind, AdaptArgs ad) {
+  __shared__ float tile[4][32][33];
+  extern __shared__ float adapt_lds[];                      // ADAPT: As | Bs | gs
+  pack_tile<TO, ADAPT>(w, O, I, k, F, f_ld, f_ts, D, d_ld, d_ts, dkind, ad, blockIdx.y * 32, blockIdx.x * 32, tile, adapt_lds);
+}
+
+// Every plain (un-adapted) weight of the model in ONE launch: block b serves the descriptor whose [block0, block0 + bx*by) range holds
+// it (binary search over the table), then runs the tile body above.  After an optimizer step all ~320 packed operands are stale at
+// once; one launch per weight was 318 launches and 2.05 ms per step, most of it launch gaps and partly filled grids.
+template <typename TO>
+__global__ __launch_bounds__(256) void pack_weight_group_kernel(const osuf_pack_desc* __restrict__ descs, int n) {
+  __shared__ float tile[4][32][33];
+  const int bid = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {                                        // last descriptor with block0 <= bid (uniform per block)
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].block0 <= bid) lo = mid; else hi = mid - 1;
+  }
+  const osuf_pack_desc d = descs[lo];
+  const int local = bid - d.block0;
+  const int bx = (d.I + 31) / 32;
+  if (local >= bx * ((d.O + 31) / 32)) return;             // uniform: before any barrier
+  const AdaptArgs none{nullptr, nullptr, nullptr, 0.f, 0};
+  pack_tile<TO, false>(d.w, d.O, d.I, d.k, (TO*)d.F, d.f_ld, d.f_tapstride, (TO*)d.D, d.d_ld, d.d_tapstride, d.dkind, none,
+                       (local / bx) * 32, (local % bx) * 32, tile, nullptr);
+}
+
 extern "C" int osuf_pack_weight(const float* w, int O, int I, int k, int out_dtype, void* F, long f_ld, long f_tapstride, void* D, long d_ld,
                                 long d_tapstride, int dkind, hipStream_t stream) {
   if (!w || O <= 0 || I <= 0 || k <= 0 || dkind < 0 || dkind > 2 || (dkind != 0 && k != 3) || (!F && !D)) return OSUF_EINVAL;
@@ -375,6 +401,16 @@ extern "C" int osuf_pack_weight(const float* w, int O, int I, int k, int out_dty
     hipLaunchKernelGGL((pack_weight_kernel<bf16_t, false>), grid, dim3(256), 0, stream, w, O, I, k, (bf16_t*)F, f_ld, f_tapstride, (bf16_t*)D, d_ld, d_tapstride, dkind, none);
   else if (out_dtype == OSUF_DT_F32)
     hipLaunchKernelGGL((pack_weight_kernel<float, false>), grid, dim3(256), 0, stream, w, O, I, k, (float*)F, f_ld, f_tapstride, (float*)D, d_ld, d_tapstride, dkind, none);
+  else return OSUF_EUNSUPPORTED;
+  return osuf_launch_status();
+}
+
+// descs: DEVICE array of n osuf_pack_desc whose block0 fields are the running sum of ceil(O/32)*ceil(I/32) (ascending, descs[0].block0 = 0);
+// total_blocks = that sum over all n.  All outputs share out_dtype.
+extern "C" int osuf_pack_weight_group(const osuf_pack_desc* descs, int n, int total_blocks, int out_dtype, hipStream_t stream) {
+  if (!descs || n <= 0 || total_blocks <= 0) return OSUF_EINVAL;
+  if (out_dtype == OSUF_DT_BF16) hipLaunchKernelGGL(pack_weight_group_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, stream, descs, n);
+  else if (out_dtype == OSUF_DT_F32) hipLaunchKernelGGL(pack_weight_group_kernel<float>, dim3(total_blocks), dim3(256), 0, stream, descs, n);
   else return OSUF_EUNSUPPORTED;
   return osuf_launch_status();
 }

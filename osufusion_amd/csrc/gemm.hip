@@ -1412,10 +1412,10 @@ static int gemm_nt_launch(int dtype, const void* A, long lda, const void* W, lon
   const int lds = 2 * kStageBytes + 512;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   const bool noskinny = getenv("OSUF_GEMM_NOSKINNY") != nullptr;

@@ -5,6 +5,7 @@ stay fp32 masters; GEMM operands are packed per (layout, dtype) and cached until
 """
 from __future__ import annotations
 
+import weakref
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -24,7 +25,7 @@ class PackCache:
     """Per-module cache of GEMM-ready weight layouts, invalidated when any source parameter changes."""
 
     def __init__(self) -> None:
-        self._d: Dict[Tuple, Tuple[Tuple, torch.Tensor]] = {}
+        self._d: Dict[Tuple, Tuple] = {}          # key -> (version, value, grouped-refresh job or None)
 
     def get(self, key: Tuple, params: Tuple[torch.Tensor, ...], builder) -> torch.Tensor:
         ver = (_WEIGHT_EPOCH, *[(p._version, p.data_ptr()) for p in params])
@@ -33,15 +34,18 @@ class PackCache:
             return hit[1]
         with torch.no_grad():
             t = builder().contiguous()
-        self._d[key] = (ver, t)
+        self._d[key] = (ver, t, None)
         return t
 
     def packs(self, key: Tuple, params: Tuple[torch.Tensor, ...], weights, kind: str, dt: torch.dtype):
         """(fwd [k][O][I], dgrad [k'][I][O]) operands of a weight -- or of several weights stacked along O (the fused q|kv
-        projection) -- built from the fp32 masters by one osuf_pack_weight launch per weight and cached like get()."""
+        projection) -- built from the fp32 masters by one osuf_pack_weight launch per weight and cached like get().  Packs whose
+        sources are plain fp32 leaf parameters also register with the grouped refresh (refresh_packs)."""
         ver = (_WEIGHT_EPOCH, *[(p._version, p.data_ptr()) for p in params])
         hit = self._d.get(key)
         if hit is not None and hit[0] == ver:
+            if hit[2] is not None:
+                hit[2].used = True
             return hit[1]
         ws = weights if isinstance(weights, (tuple, list)) else (weights,)
         with torch.no_grad():
@@ -58,8 +62,69 @@ class PackCache:
                     _pack_one(w, dt, kind, fwd=fwd, dgrad=dgr, row_offset=off)
                     off += w.shape[0]
                 pair = (fwd, dgr)
-        self._d[key] = (ver, pair)
+        job = None
+        if all(_plain_master(w) for w in ws):
+            job = _PackJob(self, key, tuple(params), tuple(ws), kind, dt, pair)
+            _PACK_JOBS[(id(self), key)] = job
+        self._d[key] = (ver, pair, job)
         return pair
+
+
+def _plain_master(w) -> bool:
+    """A weight the grouped refresh can re-read in place: an fp32, contiguous leaf parameter (not an adapter's effective weight,
+    not a tensor derived from parameters such as a merged stem)."""
+    return (isinstance(w, torch.Tensor) and w.is_leaf and w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda)
+
+
+class _PackJob:
+    """One cached pack of plain master weights: enough to re-run it from a descriptor table and re-validate its cache entry."""
+    __slots__ = ("cache", "key", "params", "ws", "kind", "dt", "pair", "used")
+
+    def __init__(self, cache, key, params, ws, kind, dt, pair) -> None:
+        self.cache, self.key, self.params, self.ws, self.kind, self.dt, self.pair = weakref.ref(cache), key, params, ws, kind, dt, pair
+        self.used = True
+
+
+_PACK_JOBS: Dict[Tuple, _PackJob] = {}
+_PACK_TABLES: Dict[torch.dtype, Tuple] = {}          # dtype -> (signature, device table, n, total blocks)
+
+
+def refresh_packs() -> int:
+    """Re-pack, in ONE launch per compute dtype, every registered weight pack that was used since the last refresh, and mark those
+    cache entries valid for the current parameters.  Called by the Trainer right after the optimizer step (all ~320 packed
+    operands go stale together there; one osuf_pack_weight launch each was 2 ms per step).  Packs it does not cover (adapter
+    weights, merged stems) and packs not used last step are rebuilt lazily by PackCache as before.  -> number of packs refreshed."""
+    by_dt: Dict[torch.dtype, list] = {}
+    for k, job in list(_PACK_JOBS.items()):
+        cache = job.cache()
+        ent = cache._d.get(job.key) if cache is not None else None
+        if ent is None or ent[2] is not job:                      # module gone, or the entry was rebuilt under another job
+            del _PACK_JOBS[k]
+            continue
+        if job.used:
+            by_dt.setdefault(job.dt, []).append(job)
+    done = 0
+    with torch.no_grad():
+        for dt, jobs in by_dt.items():
+            sig = tuple((id(j), tuple(w.data_ptr() for w in j.ws)) for j in jobs)
+            tab = _PACK_TABLES.get(dt)
+            if tab is None or tab[0] != sig:
+                items = []
+                for j in jobs:
+                    off = 0
+                    for w in j.ws:
+                        items.append((w.detach(), j.kind, j.pair[0], j.pair[1], off))
+                        off += w.shape[0]
+                dev, n, blocks = ops.pack_desc_table(items, dt, jobs[0].ws[0].device)
+                tab = (sig, dev, n, blocks)
+                _PACK_TABLES[dt] = tab
+            ops.pack_weight_group(tab[1], tab[2], tab[3], dt)
+            for j in jobs:
+                ver = (_WEIGHT_EPOCH, *[(p._version, p.data_ptr()) for p in j.params])
+                j.cache()._d[j.key] = (ver, j.pair, j)
+                j.used = False
+            done += len(jobs)
+    return done
 
 
 def _pack_one(w, dt, kind, **kw):

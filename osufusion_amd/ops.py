@@ -7,6 +7,7 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -530,11 +531,8 @@ def skinny_bwd(dy: torch.Tensor, y: Optional[torch.Tensor], x: torch.Tensor, w: 
 _DKIND = {"same": 0, "down": 1, "up": 2}
 
 
-def pack_weight(w: torch.Tensor, dtype: torch.dtype, kind: str = "same", want_fwd: bool = True, want_dgrad: bool = True,
-                fwd: Optional[torch.Tensor] = None, dgrad: Optional[torch.Tensor] = None, row_offset: int = 0, adapt=None):
-    """fp32 (O, I[, k]) master -> (fwd [k][O][I], dgrad [k'][I][O]) GEMM operands in `dtype`, one launch.  With fwd / dgrad
-    given, this weight's rows are written at row_offset of a larger stacked operand (the fused q|kv projection).
-    adapt = (lora_A, lora_B, g or None, scaling): pack the LoRA / DoRA effective weight g*(w + s*BA) instead of w."""
+def _pack_geometry(w: torch.Tensor, dtype: torch.dtype, kind: str, want_fwd: bool, want_dgrad: bool, fwd, dgrad, row_offset: int):
+    """Destinations (allocated when not given) and the pointer / stride arguments osuf_pack_weight takes for them."""
     assert w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda
     O, I = w.shape[0], w.shape[1]
     k = w.shape[2] if w.dim() == 3 else 1
@@ -553,6 +551,15 @@ def pack_weight(w: torch.Tensor, dtype: torch.dtype, kind: str = "same", want_fw
         assert dgrad.dtype == dtype and dgrad.is_contiguous() and dgrad.shape[0] == kd and dgrad.shape[1] == I
         d_ld, d_ts = dgrad.shape[2], I * dgrad.shape[2]
         pd = dgrad.data_ptr() + row_offset * dgrad.element_size()
+    return fwd, dgrad, (O, I, k, pf, f_ld, f_ts, pd, d_ld, d_ts, _DKIND[kind])
+
+
+def pack_weight(w: torch.Tensor, dtype: torch.dtype, kind: str = "same", want_fwd: bool = True, want_dgrad: bool = True,
+                fwd: Optional[torch.Tensor] = None, dgrad: Optional[torch.Tensor] = None, row_offset: int = 0, adapt=None):
+    """fp32 (O, I[, k]) master -> (fwd [k][O][I], dgrad [k'][I][O]) GEMM operands in `dtype`, one launch.  With fwd / dgrad
+    given, this weight's rows are written at row_offset of a larger stacked operand (the fused q|kv projection).
+    adapt = (lora_A, lora_B, g or None, scaling): pack the LoRA / DoRA effective weight g*(w + s*BA) instead of w."""
+    fwd, dgrad, (O, I, k, pf, f_ld, f_ts, pd, d_ld, d_ts, dk) = _pack_geometry(w, dtype, kind, want_fwd, want_dgrad, fwd, dgrad, row_offset)
     if adapt is not None:
         a, b, g, scaling = adapt
         r = a.shape[0]
@@ -560,10 +567,34 @@ def pack_weight(w: torch.Tensor, dtype: torch.dtype, kind: str = "same", want_fw
             assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
         assert a.numel() == r * I * k and b.numel() == O * r and (g is None or (g.dtype == torch.float32 and g.numel() == O))
         call("osuf_pack_weight_adapted", _p(w), _p(a), _p(b), _p(g), float(scaling), r, O, I, k, 1 if dtype == torch.bfloat16 else 0,
-             pf, f_ld, f_ts, pd, d_ld, d_ts, _DKIND[kind], _stream())
+             pf, f_ld, f_ts, pd, d_ld, d_ts, dk, _stream())
     else:
-        call("osuf_pack_weight", _p(w), O, I, k, 1 if dtype == torch.bfloat16 else 0, pf, f_ld, f_ts, pd, d_ld, d_ts, _DKIND[kind], _stream())
+        call("osuf_pack_weight", _p(w), O, I, k, 1 if dtype == torch.bfloat16 else 0, pf, f_ld, f_ts, pd, d_ld, d_ts, dk, _stream())
     return (fwd if want_fwd else None), (dgrad if want_dgrad else None)
+
+
+# osuf_pack_desc (include/osufusion_hip.h), 80 bytes
+PACK_DESC = np.dtype([("w", "<u8"), ("F", "<u8"), ("D", "<u8"), ("f_ld", "<i8"), ("f_ts", "<i8"), ("d_ld", "<i8"), ("d_ts", "<i8"),
+                      ("O", "<i4"), ("I", "<i4"), ("k", "<i4"), ("dkind", "<i4"), ("block0", "<i4"), ("reserved", "<i4")])
+
+
+def pack_desc_table(items, dtype: torch.dtype, device) -> Tuple[torch.Tensor, int, int]:
+    """items: (w, kind, fwd, dgrad, row_offset) per weight, destinations already allocated (as pack_weight wrote them before).
+    -> (device table of osuf_pack_desc, n, total_blocks) for pack_weight_group."""
+    tab = np.zeros(len(items), dtype=PACK_DESC)
+    blocks = 0
+    for j, (w, kind, fwd, dgrad, row_offset) in enumerate(items):
+        _, _, (O, I, k, pf, f_ld, f_ts, pd, d_ld, d_ts, dk) = _pack_geometry(w, dtype, kind, fwd is not None, dgrad is not None, fwd, dgrad, row_offset)
+        tab[j] = (w.data_ptr(), pf or 0, pd or 0, f_ld, f_ts, d_ld, d_ts, O, I, k, dk, blocks, 0)
+        blocks += -(-O // 32) * -(-I // 32)
+    dev = torch.from_numpy(tab.view(np.uint8)).to(device)
+    return dev, len(items), blocks
+
+
+def pack_weight_group(table: torch.Tensor, n: int, total_blocks: int, dtype: torch.dtype) -> None:
+    """osuf_pack_weight for every descriptor of the table in one launch."""
+    assert table.is_cuda and table.dtype == torch.uint8 and table.numel() == n * PACK_DESC.itemsize
+    call("osuf_pack_weight_group", table.data_ptr(), n, total_blocks, 1 if dtype == torch.bfloat16 else 0, _stream())
 
 
 def dora_gain(w: torch.Tensor, a: torch.Tensor, b: torch.Tensor, mag: Optional[torch.Tensor], scaling: float):

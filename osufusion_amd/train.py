@@ -333,6 +333,7 @@ class Trainer:
         if self._reorder_pending:
             self._reorder_pending = False
             self.apply_observed_order()
+        Fn.refresh_packs()                                  # every packed GEMM operand went stale with that step: one grouped launch
         return loss.detach(), total_norm
 
     def apply_observed_order(self) -> None:

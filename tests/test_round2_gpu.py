@@ -283,3 +283,43 @@ def test_trainer_gradient_accumulation_and_relayout(golden_dir):
         assert e < 2e-2, e                                             # second step: same trajectory up to Adam's sign noise on ~0 gradients
     finally:
         Fn.enable_direct_grads(False)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_grouped_weight_pack_equals_per_weight_pack(golden_dir, dt):
+    """osuf_pack_weight_group (one launch for every plain master weight, run by Trainer.step after the optimizer) writes exactly
+    what one osuf_pack_weight launch per weight writes, and leaves every refreshed cache entry valid for the updated parameters."""
+    from osufusion_amd.pattern import synth_inputs
+    from osufusion_amd.train import Trainer
+    x, a, c, t, noise = (torch.from_numpy(v).to(DEV) for v in synth_inputs("packs", 2, 256))
+    try:
+        _, _, m = _build_model("unet_tiny", golden_dir)
+        tr = Trainer(m, lr=1e-2, clip_grad_norm=1.0, compute_dtype=dt, reorder_buckets=False)
+        tr.step(x, a, c, noise, t)                                     # registers the jobs (lazy packs) and ends with one grouped refresh
+        jobs = [j for j in Fn._PACK_JOBS.values() if j.cache() is not None and j.dt == dt]
+        assert len(jobs) >= 20
+        before = {id(j): j.pair[0].clone() for j in jobs}
+        calls = []
+        orig = ops.call
+        ops.call = lambda name, *args, **kw: (calls.append(name), orig(name, *args, **kw))[1]
+        try:
+            tr.step(x, a, c, noise, t)
+        finally:
+            ops.call = orig
+        assert calls.count("osuf_pack_weight_group") == 1
+        lazy = calls.count("osuf_pack_weight")
+        assert lazy <= 8, f"{lazy} per-weight packs left in a steady-state step (derived weights only: merged stems, Parallel sum, head)"
+        changed = 0
+        for j in jobs:
+            ent = j.cache()._d[j.key]
+            assert ent[2] is j and ent[0][0] == Fn._WEIGHT_EPOCH            # valid for the parameters as they are now
+            off = 0
+            for w in j.ws:
+                f, d = ops.pack_weight(w.detach(), dt, j.kind)
+                O = w.shape[0]
+                assert torch.equal(j.pair[0][:, off:off + O], f) and torch.equal(j.pair[1][:, :, off:off + O], d), j.key
+                off += O
+            changed += int(not torch.equal(before[id(j)], j.pair[0]))
+        assert changed >= len(jobs) // 2                                # the optimizer did move the weights the table re-read
+    finally:
+        Fn.enable_direct_grads(False)
