@@ -84,7 +84,8 @@ def test_mfma_layout_exact_integers(dtype):
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("M,N,K,in_act,out_act", [(32, 128, 256, 0, 0), (32, 256, 128, 1, 2), (2, 64, 5, 0, 0), (48, 72, 200, 1, 0),
-                                                  (64, 1024, 1024, 1, 2), (7, 33, 17, 0, 2)])
+                                                  (64, 1024, 1024, 1, 2), (7, 33, 17, 0, 2), (32, 512, 2048, 1, 0), (5, 40, 24, 1, 2),
+                                                  (33, 264, 136, 0, 2)])
 def test_skinny_linear_kernels(dtype, tol, M, N, K, in_act, out_act):
     """osuf_skinny_fwd / _bwd (embedding-sized MLPs, fp32 masters read in place) vs torch: y, dx, dW, db; M not a multiple of 32,
     K not a multiple of 8 (cond_mlp.0 has K=5), fused input SiLU / output sigmoid and their derivatives."""
