@@ -113,9 +113,12 @@ int osuf_gate_residual(int dtype, const void* h, long ldh, const float* gate, co
                        int M, int C, int L, hipStream_t stream);
 int osuf_gca_bwd_apply(int dtype, const void* dout, long lddo, const void* h, long ldh, void* dh, long lddh, const float* p,
                        const float* gate, const float* dpooled, const float* sdot, const float* wk, float* dlogit,
-                       int M, int C, int L, float* dwk, float* dbk, hipStream_t stream);
+                       int M, int C, int L, float* dwk, float* dbk, float* workspace, long workspace_bytes, hipStream_t stream);
+long osuf_gca_bwd_apply_workspace_bytes(int M, int C);
 /* (dwk [C] / dbk [1], optional, accumulated into: sum_m dlogit[m] * h[m][:] and sum_m dlogit[m], the gradients of to_k's weight and
- *  bias (residual.py:20,29), from the h rows osuf_gca_bwd_apply already holds.) */
+ *  bias (residual.py:20,29), from the h rows osuf_gca_bwd_apply already holds.  With a workspace of
+ *  osuf_gca_bwd_apply_workspace_bytes the per-workgroup partials go through a slab and a small second kernel; without it
+ *  (NULL / too small) thousands of workgroups add to the same C addresses with atomics, which costs 25-40 us per launch.) */
 
 /* ---- attention (attn.hip) -----------------------------------------------------------------------------------
  * replaces: RotaryPositionEmbedding.forward + apply_rotary_pos_emb (modules/attention.py:52-58, utils.py:25-32) and

@@ -35,7 +35,8 @@ SIGNATURES = {
     "osuf_gn_stats": [I, P, L, P, P, I, I, I, P],
     "osuf_gn_stats_workspace_bytes": [I, I, I],
     "osuf_gate_residual": [I, P, L, P, P, L, P, L, I, I, I, P],
-    "osuf_gca_bwd_apply": [I, P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, P, P, P],
+    "osuf_gca_bwd_apply": [I, P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, P, P, P, L, P],
+    "osuf_gca_bwd_apply_workspace_bytes": [I, I],
     "osuf_rope_cast": [I, P, L, P, L, P, P, I, I, I, I, I, P],
     "osuf_rope_bwd": [I, P, L, P, L, P, P, I, I, I, I, I, P],
     "osuf_mqa_fwd": [P, L, P, L, P, L, P, L, I, P, I, I, I, I, F, P],

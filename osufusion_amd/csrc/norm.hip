@@ -141,20 +141,30 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* dh, long ld
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = 0.f; sh[e] = 0.f; }
     if (ss) { load8(ss + (long)b * 2 * C + c, sc); load8(ss + (long)b * 2 * C + C + c, sh); }
-    for (int n = n_begin + rl; n < n_end; n += cg.rp) {
-      const long m = (long)b * L + n;
-      float v[8], d[8];
-      load8(y + m * ldy + c, v);
-      load8(dh + m * lddh + c, d);
+    // four row steps per trip, their eight 16-byte loads issued together (rows clamped, the surplus masked out below): one step
+    // per trip kept 8 KB in flight per CU at the deep levels (C = 1024: 2 rows per step, 256 workgroups) and ran at 1.5 TB/s
+    for (int n0 = n_begin + rl; n0 < n_end; n0 += 4 * cg.rp) {
+      float v[4][8], d[4][8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float xh = (v[e] - mean) * rstd;
-        float u = (xh * g[e] + bt[e]) * (1.f + sc[e]) + sh[e];
-        float du = d[e] * silu_grad_f(u);
-        t1[e] += du * xh;
-        t2[e] += du;
-        t3[e] += xh;
-        t4[e] += xh * xh;
+      for (int q = 0; q < 4; ++q) {
+        const long m = (long)b * L + min(n0 + q * cg.rp, n_end - 1);
+        load8(y + m * ldy + c, v[q]);
+        load8(dh + m * lddh + c, d[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = n0 + q * cg.rp < n_end;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float xh = (v[q][e] - mean) * rstd;
+          float u = (xh * g[e] + bt[e]) * (1.f + sc[e]) + sh[e];
+          float du = ok ? d[q][e] * silu_grad_f(u) : 0.f;
+          xh = ok ? xh : 0.f;
+          t1[e] += du * xh;
+          t2[e] += du;
+          t3[e] += xh;
+          t4[e] += xh * xh;
+        }
       }
     }
   }
@@ -480,19 +490,21 @@ __global__ __launch_bounds__(256) void wcolsum_kernel(const T* a, long lda, cons
   const int n_begin = blockIdx.x * rows_per_block, n_end = min(L, n_begin + rows_per_block);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (rl < cg.rp) {
-    for (int n = n_begin + rl; n < n_end; n += cg.rp) {
-      const long m = (long)b * L + n;
-      float v[8];
-      load8(a + m * lda + c, v);
-      if (bmul) {
-        float u[8];
-        load8(bmul + m * ldb + c, u);
+    for (int n0 = n_begin + rl; n0 < n_end; n0 += 4 * cg.rp) {       // four row steps per trip, loads first (see gn_bwd_reduce_kernel)
+      float v[4][8], u[4][8], wv[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= u[e];
+      for (int q = 0; q < 4; ++q) {
+        const long m = (long)b * L + min(n0 + q * cg.rp, n_end - 1);
+        load8(a + m * lda + c, v[q]);
+        if (bmul) load8(bmul + m * ldb + c, u[q]);                     // (uniform conditions: no exec mask)
+        wv[q] = w ? w[m] : 1.f;
       }
-      const float wv = w ? w[m] : 1.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += wv * v[e];
+      for (int q = 0; q < 4; ++q) {
+        const float wq = n0 + q * cg.rp < n_end ? wv[q] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += wq * (bmul ? v[q][e] * u[q][e] : v[q][e]);
+      }
     }
   }
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -547,61 +559,67 @@ __global__ __launch_bounds__(256) void gate_residual_kernel(const T* h, long ldh
 // dwk / dbk (optional, accumulated into): the gradients of the pooling logits' weight and bias, sum_m dlogit[m] * h[m][:] and
 // sum_m dlogit[m] -- taken from the h row this kernel already holds in registers (round 1 re-read h in a wcolsum pass and
 // summed dlogit with two torch reductions: 3 launches and one pass over h per block)
-template <typename T>
+// NCH = channel chunks (8 elements) per lane = ceil(C/8 / G), a template parameter so that the row loop has no branch at all: the
+// h and dout rows of an iteration are fetched together up front (row and chunk indices clamped, surplus lanes masked by selects).
+// The first version loaded h under `if (row ok && chunk ok)`, reduced, then loaded dout under a second such branch: two exposed
+// memory round trips per pair of rows, and with the dwk accumulators (fewer waves per CU) 51 us per launch for 200 MB.
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void gca_bwd_apply_kernel(const T* dout, long lddo, const T* h, long ldh, T* dh, long lddh,
                                                             const float* p, const float* gate, const float* dpooled,
                                                             const float* sdot, const float* wk, float* dlogit,
-                                                            int M, int C, int L, int G, float* dwk, float* dbk) {
+                                                            int M, int C, int L, int G, float* dwk, float* dbk, float* part) {
   const int chunks = C >> 3;
   const int rows_per_wave = 64 / G;
   const int lane = threadIdx.x & 63, gl = lane % G, gr = lane / G;
   const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int waves_total = (gridDim.x * blockDim.x) >> 6;
-  float aw[kMaxCh][8], ab = 0.f;
+  float aw[NCH][8], wv8[NCH][8], ab = 0.f;
+  int cofs[NCH];
+  bool cok[NCH];
 #pragma unroll
-  for (int j = 0; j < kMaxCh; ++j)
+  for (int j = 0; j < NCH; ++j) {
+    cok[j] = gl + j * G < chunks;
+    cofs[j] = min(gl + j * G, chunks - 1) * 8;
+    load8(wk + cofs[j], wv8[j]);
 #pragma unroll
     for (int e = 0; e < 8; ++e) aw[j][e] = 0.f;
+  }
   for (long m0 = (long)wave_global * rows_per_wave; m0 < M; m0 += (long)waves_total * rows_per_wave) {
     const long m = m0 + gr;
     const bool rok = m < M;
-    const long b = rok ? m / L : 0;
-    float hv[kMaxCh][8];
+    const long mc = rok ? m : M - 1;
+    const long b = mc / L;
+    float hv[NCH][8], dv[NCH][8], dp[NCH][8], g[NCH][8];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      load8(h + mc * ldh + cofs[j], hv[j]);
+      load8(dout + mc * lddo + cofs[j], dv[j]);
+      load8(dpooled + b * C + cofs[j], dp[j]);
+      load8(gate + b * C + cofs[j], g[j]);
+    }
+    const float pm = p[mc], sd = sdot[b];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < kMaxCh; ++j) {
-      const int ch = gl + j * G;
-      if (rok && ch < chunks) {
-        float dp[8];
-        load8(h + m * ldh + ch * 8, hv[j]);
-        load8(dpooled + b * C + ch * 8, dp);
+    for (int j = 0; j < NCH; ++j) {
+      float sj = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += hv[j][e] * dp[e];
-      }
+      for (int e = 0; e < 8; ++e) sj += hv[j][e] * dp[j][e];
+      s += cok[j] ? sj : 0.f;
     }
     s = group_sum_dyn(s, G);
-    if (rok) {
-      const float pm = p[m];
-      const float dl = pm * (s - sdot[b]);
-      if (gl == 0) { dlogit[m] = dl; ab += dl; }
+    const float dl = pm * (s - sd);
+    if (rok && gl == 0) dlogit[m] = dl;
+    ab += (rok && gl == 0) ? dl : 0.f;
 #pragma unroll
-      for (int j = 0; j < kMaxCh; ++j) {
-        const int ch = gl + j * G;
-        if (ch < chunks) {
-          if (dwk) {
+    for (int j = 0; j < NCH; ++j) {
+      const bool ok = rok && cok[j];
+      float o[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) aw[j][e] += dl * hv[j][e];
-          }
-          float d[8], g[8], dp[8], w[8], o[8];
-          load8(dout + m * lddo + ch * 8, d);
-          load8(gate + b * C + ch * 8, g);
-          load8(dpooled + b * C + ch * 8, dp);
-          load8(wk + ch * 8, w);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = d[e] * g[e] + pm * dp[e] + dl * w[e];
-          store8(dh + m * lddh + ch * 8, o);
-        }
+      for (int e = 0; e < 8; ++e) {
+        aw[j][e] += ok ? dl * hv[j][e] : 0.f;
+        o[e] = dv[j][e] * g[j][e] + pm * dp[j][e] + dl * wv8[j][e];
       }
+      if (ok) store8(dh + m * lddh + cofs[j], o);
     }
   }
   if (dwk) {                                               // uniform: rows of a wave (lanes with equal gl) -> waves of the block -> atomics
@@ -609,7 +627,7 @@ __global__ __launch_bounds__(256) void gca_bwd_apply_kernel(const T* dout, long 
     float* red = reinterpret_cast<float*>(smem_gca);       // [4][C] | [4]
     for (int off = G; off < 64; off <<= 1) {
 #pragma unroll
-      for (int j = 0; j < kMaxCh; ++j)
+      for (int j = 0; j < NCH; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) aw[j][e] += __shfl_xor(aw[j][e], off, 64);
       ab += __shfl_xor(ab, off, 64);
@@ -617,18 +635,50 @@ __global__ __launch_bounds__(256) void gca_bwd_apply_kernel(const T* dout, long 
     const int wv = threadIdx.x >> 6;
     if (gr == 0) {
 #pragma unroll
-      for (int j = 0; j < kMaxCh; ++j) {
-        const int ch = gl + j * G;
-        if (ch < chunks) {
+      for (int j = 0; j < NCH; ++j) {
+        if (cok[j]) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) red[wv * C + ch * 8 + e] = aw[j][e];
+          for (int e = 0; e < 8; ++e) red[wv * C + cofs[j] + e] = aw[j][e];
         }
       }
       if (gl == 0) red[4 * C + wv] = ab;
     }
     __syncthreads();
-    for (int cc = threadIdx.x; cc < C; cc += blockDim.x) atomic_add_f32(dwk + cc, (red[cc] + red[C + cc]) + (red[2 * C + cc] + red[3 * C + cc]));
-    if (threadIdx.x == 0 && dbk) atomic_add_f32(dbk, (red[4 * C] + red[4 * C + 1]) + (red[4 * C + 2] + red[4 * C + 3]));
+    // every workgroup holds a partial of the SAME C (+1) sums: added straight into dwk, a few thousand adders queue on each address
+    // (~12 ns per atomic and address: +25-40 us per launch, measured) -- so the partials go to a [blocks][C + 1] slab (plain stores)
+    // and gca_dwk_reduce_kernel sums them; the atomic form remains for callers without a workspace
+    for (int cc = threadIdx.x; cc < C; cc += blockDim.x) {
+      const float v = (red[cc] + red[C + cc]) + (red[2 * C + cc] + red[3 * C + cc]);
+      if (part) part[(long)blockIdx.x * (C + 1) + cc] = v; else atomic_add_f32(dwk + cc, v);
+    }
+    if (threadIdx.x == 0) {
+      const float v = (red[4 * C] + red[4 * C + 1]) + (red[4 * C + 2] + red[4 * C + 3]);
+      if (part) part[(long)blockIdx.x * (C + 1) + C] = v; else if (dbk) atomic_add_f32(dbk, v);
+    }
+  }
+}
+
+// dwk[c] += sum_i part[i][c], dbk += sum_i part[i][C]: grid (ceil((C+1)/64), 16); a workgroup = 64 columns x 4 row lanes over its
+// sixteenth of the rows, eight loads in flight per lane; the 16 row slices meet by atomics (16 adders per address)
+__global__ __launch_bounds__(256) void gca_dwk_reduce_kernel(const float* __restrict__ part, int nrows, int C, float* dwk, float* dbk) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int per = (nrows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(nrows, r0 + per);
+  const int cc = min(col, C);
+  float s = 0.f;
+  for (int r = r0 + rl; r < r1; r += 32) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = part[(long)min(r + 4 * q, r1 - 1) * (C + 1) + cc];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += r + 4 * q < r1 ? v[q] : 0.f;
+  }
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col <= C) {
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (col < C) atomic_add_f32(dwk + col, t); else if (dbk) atomic_add_f32(dbk, t);
   }
 }
 
@@ -775,15 +825,30 @@ extern "C" int osuf_gate_residual(int dtype, const void* h, long ldh, const floa
   return osuf_launch_status();
 }
 
+static inline int gca_blocks(int M, int C, bool dwk) {
+  int blocks = row_grid(M, pick_group(C / 8));
+  if (dwk && blocks > 2048) blocks = 2048;                 // bounds the dwk partials (C + 1 per block)
+  return blocks;
+}
+/* bytes of workspace that let osuf_gca_bwd_apply sum its dwk / dbk partials through a slab instead of same-address atomics */
+extern "C" long osuf_gca_bwd_apply_workspace_bytes(int M, int C) {
+  if (M <= 0 || bad_c(C)) return 0;
+  return (long)gca_blocks(M, C, true) * (C + 1) * (long)sizeof(float);
+}
+
 extern "C" int osuf_gca_bwd_apply(int dtype, const void* dout, long lddo, const void* h, long ldh, void* dh, long lddh, const float* p,
                                   const float* gate, const float* dpooled, const float* sdot, const float* wk, float* dlogit,
-                                  int M, int C, int L, float* dwk, float* dbk, hipStream_t stream) {
+                                  int M, int C, int L, float* dwk, float* dbk, float* workspace, long workspace_bytes, hipStream_t stream) {
   if (bad_c(C) || M <= 0 || L <= 0 || M % L || lddo % 8 || ldh % 8 || lddh % 8 || (dbk && !dwk)) return OSUF_EINVAL;
   const int G = pick_group(C / 8);
   const size_t lds = dwk ? (size_t)(4 * C + 4) * sizeof(float) : 0;
-  int blocks = row_grid(M, G);
-  if (dwk && blocks > 1024) blocks = 1024;                 // bounds the dwk atomics (C per block)
-  DISPATCH_T(dtype, hipLaunchKernelGGL(gca_bwd_apply_kernel<T>, dim3(blocks), dim3(256), lds, stream, (const T*)dout, lddo,
-                                       (const T*)h, ldh, (T*)dh, lddh, p, gate, dpooled, sdot, wk, dlogit, M, C, L, G, dwk, dbk));
+  const int blocks = gca_blocks(M, C, dwk != nullptr);
+  float* part = (dwk && workspace && workspace_bytes >= (long)blocks * (C + 1) * (long)sizeof(float)) ? workspace : nullptr;
+  const int nch = (C / 8 + G - 1) / G;                     // 1..4 (C <= 2048, G = 64 from 512 channels on)
+#define GCA_LAUNCH(NCH) DISPATCH_T(dtype, hipLaunchKernelGGL((gca_bwd_apply_kernel<T, NCH>), dim3(blocks), dim3(256), lds, stream, \
+    (const T*)dout, lddo, (const T*)h, ldh, (T*)dh, lddh, p, gate, dpooled, sdot, wk, dlogit, M, C, L, G, dwk, dbk, part))
+  if (nch == 1) { GCA_LAUNCH(1); } else if (nch == 2) { GCA_LAUNCH(2); } else if (nch == 3) { GCA_LAUNCH(3); } else { GCA_LAUNCH(4); }
+#undef GCA_LAUNCH
+  if (part) hipLaunchKernelGGL(gca_dwk_reduce_kernel, dim3((C + 1 + 63) / 64, 16), dim3(256), 0, stream, part, blocks, C, dwk, dbk);
   return osuf_launch_status();
 }

@@ -354,8 +354,12 @@ def gca_bwd_apply(dout, h, p, gate, dpooled, sdot, wk, L: int, dwk_out: Optional
     M, C, ld = _rows(h)
     dh = torch.empty(h.shape, dtype=h.dtype, device=h.device)
     dlogit = torch.empty(M, dtype=torch.float32, device=h.device)
+    ws, need = None, 0
+    if dwk_out is not None:
+        need = _lib.load().osuf_gca_bwd_apply_workspace_bytes(M, C)
+        ws = torch.empty(need // 4, dtype=torch.float32, device=h.device)
     call("osuf_gca_bwd_apply", dt_of(h), _p(dout), _rows(dout)[2], _p(h), ld, _p(dh), C, _p(p), _p(gate), _p(dpooled), _p(sdot), _p(wk),
-         _p(dlogit), M, C, L, _p(dwk_out), _p(dbk_out), _stream())
+         _p(dlogit), M, C, L, _p(dwk_out), _p(dbk_out), _p(ws), need, _stream())
     return dh, dlogit
 
 
