@@ -242,6 +242,28 @@ int osuf_skinny_bwd(int mode, const float* dy, long lddy, const float* y, long l
                     float* dx, long lddx, float* dW, float* db, int M, int N, int K, int in_act, int out_act, int accumulate,
                     hipStream_t stream);
 
+/* Group forms for linears that share ONE input x (M, K) -- the FiLM projections: every ResidualBlock applies
+ * Sequential(SiLU, Linear(2048, 2C)) to the same embedding (residual.py:104-111, 35 of them per forward).  descs: DEVICE array.
+ *   osuf_skinny_fwd_group: y_i = in_act(x) W_i^T + b_i for all i in one launch; block0 = running sum of ceil(N_i / 32).
+ *   osuf_skinny_dx_group : dx = in_act'(x) * sum_i dy_i W_i (dx overwritten);      block0 = running sum of ceil(N_i / 512).
+ * K and every N_i multiples of 8, rows 16-byte aligned (OSUF_EINVAL otherwise: use the per-linear entry points).  The weight
+ * gradients stay per linear (osuf_skinny_bwd with dx == NULL), so each is complete as soon as its block's backward has run. */
+#ifndef OSUF_LINEAR_DESC_DEFINED
+#define OSUF_LINEAR_DESC_DEFINED
+typedef struct osuf_linear_desc {
+  const float* W;          /* (N, K) fp32 master weight */
+  const float* bias;       /* (N) or NULL */
+  float* y;                /* forward output rows, row stride ldy */
+  const float* dy;         /* backward: gradient of y, row stride lddy */
+  long ldy, lddy;
+  int N, block0;
+} osuf_linear_desc;                                 /* 56 bytes */
+#endif
+int osuf_skinny_fwd_group(int mode, const float* x, long ldx, const osuf_linear_desc* descs, int n, int total_blocks, int M, int K,
+                          int in_act, hipStream_t stream);
+int osuf_skinny_dx_group(int mode, const osuf_linear_desc* descs, int n, int total_slices, const float* x, long ldx, float* dx, long lddx,
+                         int M, int K, int in_act, hipStream_t stream);
+
 /* ---- audio front end (audio.hip)    replaces: scripts/dataset_creator.py:36-55 load_audio's feature step,
  *      np.log(np.abs(librosa.vqt(y, sr=22050, hop_length=176, fmin=C0, n_bins=96, bins_per_octave=12)) + 1e-10)
  *      (called from trainer.py:104, trainer_peft.py:107, inference_gradio.py:56).

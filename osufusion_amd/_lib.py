@@ -70,6 +70,8 @@ SIGNATURES = {
     "osuf_frame_rows": [P, L, I, I, P, L, P],
     "osuf_skinny_fwd": [I, P, L, P, P, P, L, I, I, I, I, I, P],
     "osuf_skinny_bwd": [I, P, L, P, L, P, L, P, P, L, P, P, I, I, I, I, I, I, P],
+    "osuf_skinny_fwd_group": [I, P, L, P, I, I, I, I, I, P],
+    "osuf_skinny_dx_group": [I, P, I, I, P, L, P, L, I, I, I, P],
 }
 
 _lib = None

@@ -16,6 +16,19 @@ typedef struct osuf_pack_desc {
 } osuf_pack_desc;
 #endif
 static_assert(sizeof(osuf_pack_desc) == 80, "osuf_pack_desc is part of the C ABI");
+// descriptor of the osuf_skinny_*_group entry points (same definition in include/osufusion_hip.h)
+#ifndef OSUF_LINEAR_DESC_DEFINED
+#define OSUF_LINEAR_DESC_DEFINED
+typedef struct osuf_linear_desc {
+  const float* W;          /* (N, K) fp32 master weight */
+  const float* bias;       /* (N) or NULL */
+  float* y;                /* forward output rows, row stride ldy */
+  const float* dy;         /* backward: gradient of y, row stride lddy */
+  long ldy, lddy;
+  int N, block0;
+} osuf_linear_desc;                                 /* 56 bytes */
+#endif
+static_assert(sizeof(osuf_linear_desc) == 56, "osuf_linear_desc is part of the C ABI");
 
 #define OSUF_DT_F32 0
 #define OSUF_DT_BF16 1

@@ -1318,6 +1318,51 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, floa
   }
 }
 
+// The same reduce for many splits and few outputs (the 256-channel k3 convs of the top level: 85 partial tiles of 768 KB each, but
+// only 16 K float4 groups -> 64 workgroups in the kernel above, each lane walking 3 x 85 slabs in 64 dependent round trips:
+// 25 us).  Here a workgroup is 64 output groups x 4 split lanes: wave s sums splits s, s+4, ... (a quarter of the walk, four times
+// the workgroups), the four partial sums meet in LDS in a fixed order (s = 0..3: still deterministic).
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* ws, float* dW, long n12, int taps, int splits, int accumulate) {
+  __shared__ f32x4 red[3][3][64];                          // [split lane 1..3][tap][output group]
+  const int tq = threadIdx.x & 63, ts = threadIdx.x >> 6;
+  const long n = n12 * taps;
+  const int mine = (splits - ts + 3) >> 2;                  // splits ts, ts + 4, ...
+  if constexpr (LAYOUT == 0) {
+    const long n4 = n >> 2;
+    const long i = (long)blockIdx.x * 64 + tq;
+    const long ic = min(i, n4 - 1);
+    f32x4 a = sum_partials(ws + (long)ts * n + 4 * ic, 4 * n, mine);
+    if (ts) red[ts - 1][0][tq] = a;
+    __syncthreads();
+    if (ts == 0 && i < n4) {
+      a = ((a + red[0][0][tq]) + red[1][0][tq]) + red[2][0][tq];
+      if (accumulate) a += reinterpret_cast<f32x4*>(dW)[i];
+      reinterpret_cast<f32x4*>(dW)[i] = a;
+    }
+  } else {                                                  // taps == 3 only (the launcher checks)
+    const long q12 = n12 >> 2;
+    const long q = (long)blockIdx.x * 64 + tq;
+    const long qc = min(q, q12 - 1);
+    f32x4 a[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) a[t] = sum_partials(ws + (long)ts * n + (long)t * n12 + 4 * qc, 4 * n, mine);
+    if (ts) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) red[ts - 1][t][tq] = a[t];
+    }
+    __syncthreads();
+    if (ts == 0 && q < q12) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) a[t] = ((a[t] + red[0][t][tq]) + red[1][t][tq]) + red[2][t][tq];
+      f32x4* dst = reinterpret_cast<f32x4*>(dW + 12 * q);
+      f32x4 o0 = {a[0][0], a[1][0], a[2][0], a[0][1]}, o1 = {a[1][1], a[2][1], a[0][2], a[1][2]}, o2 = {a[2][2], a[0][3], a[1][3], a[2][3]};
+      if (accumulate) { o0 += dst[0]; o1 += dst[1]; o2 += dst[2]; }
+      dst[0] = o0; dst[1] = o1; dst[2] = o2;
+    }
+  }
+}
+
 // column sums: out[n] += sum_m Y[m][n]   (bias gradients)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* Y, long ldy, int M, int N, float* out, int rows_per_block) {
@@ -1548,9 +1593,14 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
       hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(((sp * btiles + 7) / 8) * 8 * taps), dim3(512), lds_big, stream, gb);
       if (gb.ws) {
         const long n12 = (long)N1 * N2;
-        long blocks = ((out_layout == 1 ? n12 / 4 : n / 4) + 255) / 256;
+        const long groups = out_layout == 1 ? n12 / 4 : n / 4;            // float4 output groups (x taps partial reads each in layout 1)
+        long blocks = (groups + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        if (out_layout == 1) hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((int)blocks), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
+        if (sp >= 8 && blocks < 512 && (out_layout == 0 || taps == 3)) {   // many splits, few outputs: four split lanes per output group
+          const long b4 = (groups + 63) / 64;
+          if (out_layout == 1) hipLaunchKernelGGL(wgrad_reduce4_kernel<1>, dim3((int)b4), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
+          else hipLaunchKernelGGL(wgrad_reduce4_kernel<0>, dim3((int)b4), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
+        } else if (out_layout == 1) hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((int)blocks), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
         else hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3((int)blocks), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
       }
       return osuf_launch_status();

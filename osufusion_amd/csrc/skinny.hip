@@ -59,11 +59,9 @@ __device__ __forceinline__ void sk_zero8(float (&v)[8], bool keep) {
 
 // y[m][n] = out_act( sum_k in_act(x[m][k]) W[n][k] + b[n] )
 template <int MODE, bool VEC>
-__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ W, const float* __restrict__ bias,
-                                                         float* __restrict__ y, long ldy, int M, int N, int K, int in_act, int out_act) {
-  __shared__ float red[4 * 1024];
+__device__ __forceinline__ void sk_fwd_tile(const float* __restrict__ x, long ldx, const float* __restrict__ W, const float* __restrict__ bias,
+                                            float* __restrict__ y, long ldy, int M, int N, int K, int in_act, int out_act, int n0, float* red) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
-  const int n0 = blockIdx.x * 32;
   for (int m0 = 0; m0 < M; m0 += 32) {
     f32x16 acc;
 #pragma unroll
@@ -121,6 +119,35 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
   }
 }
 
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ W, const float* __restrict__ bias,
+                                                         float* __restrict__ y, long ldy, int M, int N, int K, int in_act, int out_act) {
+  __shared__ float red[4 * 1024];
+  sk_fwd_tile<MODE, VEC>(x, ldx, W, bias, y, ldy, M, N, K, in_act, out_act, blockIdx.x * 32, red);
+}
+
+// last descriptor whose block0 <= bid (block0 ascending from 0): which linear of a group a workgroup serves
+__device__ __forceinline__ int sk_find_desc(const osuf_linear_desc* __restrict__ descs, int n, int bid) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].block0 <= bid) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// Several linears that share ONE input (the FiLM projections: every ResidualBlock applies Sequential(SiLU, Linear) to the same
+// (B, 2048) embedding, residual.py:104-111) in one launch: 35 launches of 16-64 workgroups each become one of ~1,200.
+template <int MODE>
+__global__ __launch_bounds__(256) void skinny_fwd_group_kernel(const float* __restrict__ x, long ldx, const osuf_linear_desc* __restrict__ descs, int n,
+                                                               int M, int K, int in_act) {
+  __shared__ float red[4 * 1024];
+  const osuf_linear_desc d = descs[sk_find_desc(descs, n, blockIdx.x)];
+  const int n0 = ((int)blockIdx.x - d.block0) * 32;
+  if (n0 >= d.N) return;
+  sk_fwd_tile<MODE, true>(x, ldx, d.W, d.bias, d.y, d.ldy, M, d.N, K, in_act, SK_ACT_NONE, n0, red);
+}
+
 __device__ __forceinline__ float sk_dact_from_out(int out_act, float yv) {      // derivative expressed through the OUTPUT
   return out_act == SK_ACT_SIGMOID ? yv * (1.f - yv) : 1.f;
 }
@@ -129,14 +156,11 @@ __device__ __forceinline__ float sk_dact_from_out(int out_act, float yv) {      
 // grid (K/32, nsplit): a 32-column strip of W is a strided read (128 B per row), so the N range is cut into `nsplit` slices to
 // put >= 256 workgroups on the chip; slices combine by fp32 atomics into a zeroed dx (the in_act' factor distributes over them).
 template <int MODE, bool VEC>
-__global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ y, long ldy,
-                                                        const float* __restrict__ W, const float* __restrict__ x, long ldx, float* __restrict__ dx,
-                                                        long lddx, int M, int N, int K, int in_act, int out_act, int n_per_split) {
-  __shared__ float red[4 * 1024];
+__device__ __forceinline__ void sk_dx_tile(const float* __restrict__ dy, long lddy, const float* __restrict__ y, long ldy,
+                                           const float* __restrict__ W, const float* __restrict__ x, long ldx, float* __restrict__ dx,
+                                           long lddx, int M, int N, int K, int in_act, int out_act, int k0, int n_begin, int n_end, bool atomic,
+                                           float* red) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
-  const int k0 = blockIdx.x * 32;
-  const int n_begin = blockIdx.y * n_per_split, n_end = min(N, n_begin + n_per_split);
-  const bool atomic = gridDim.y > 1;
   for (int m0 = 0; m0 < M; m0 += 32) {
     f32x16 acc;
 #pragma unroll
@@ -204,6 +228,29 @@ __global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict_
     }
     __syncthreads();
   }
+}
+
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ y, long ldy,
+                                                        const float* __restrict__ W, const float* __restrict__ x, long ldx, float* __restrict__ dx,
+                                                        long lddx, int M, int N, int K, int in_act, int out_act, int n_per_split) {
+  __shared__ float red[4 * 1024];
+  const int n_begin = blockIdx.y * n_per_split;
+  sk_dx_tile<MODE, VEC>(dy, lddy, y, ldy, W, x, ldx, dx, lddx, M, N, K, in_act, out_act, blockIdx.x * 32, n_begin, min(N, n_begin + n_per_split),
+                        gridDim.y > 1, red);
+}
+
+// dx += in_act'(x) * sum_i dy_i W_i over a group of linears with one shared input: grid (K/32, sum_i ceil(N_i / 512)); every slice
+// adds into the zeroed dx with atomics (descs[i].block0 = running sum of the slice counts)
+template <int MODE>
+__global__ __launch_bounds__(256) void skinny_dx_group_kernel(const osuf_linear_desc* __restrict__ descs, int n, const float* __restrict__ x, long ldx,
+                                                              float* __restrict__ dx, long lddx, int M, int K, int in_act) {
+  __shared__ float red[4 * 1024];
+  const osuf_linear_desc d = descs[sk_find_desc(descs, n, blockIdx.y)];
+  const int n_begin = ((int)blockIdx.y - d.block0) * 512;
+  if (n_begin >= d.N) return;
+  sk_dx_tile<MODE, true>(d.dy, d.lddy, nullptr, 0, d.W, x, ldx, dx, lddx, M, d.N, K, in_act, SK_ACT_NONE, blockIdx.x * 32, n_begin,
+                         min(d.N, n_begin + 512), true, red);
 }
 
 // dW[n][k] (+)= sum_m dz[m][n] in_act(x[m][k]) ;  db[n] += sum_m dz[m][n]      one wave per 32x32 tile, 4 tiles per workgroup
@@ -316,5 +363,30 @@ extern "C" int osuf_skinny_bwd(int mode, const float* dy, long lddy, const float
     else
       hipLaunchKernelGGL(skinny_dw_kernel<0>, grid, dim3(256), 0, stream, dy, lddy, y, ldy, x, ldx, dW, db, M, N, K, in_act, out_act, accumulate);
   }
+  return osuf_launch_status();
+}
+
+/* Group forms for linears that share one input x (M, K): descs is a DEVICE array of n osuf_linear_desc.
+ *   osuf_skinny_fwd_group: y_i = in_act(x) W_i^T + b_i for every i; block0 = running sum of ceil(N_i / 32), total_blocks = its total.
+ *   osuf_skinny_dx_group : dx = in_act'(x) * sum_i dy_i W_i (dx is overwritten); block0 = running sum of ceil(N_i / 512).
+ * Vector path only: K and every N_i multiples of 8, 16-byte aligned rows (EINVAL otherwise -- use the per-linear entry points). */
+static bool sk_group_bad(const void* x, long ldx, int M, int K, int in_act) {
+  return !x || M <= 0 || K <= 0 || K % 8 || ldx % 4 || !sk_al16(x) || (in_act != SK_ACT_NONE && in_act != SK_ACT_SILU);
+}
+extern "C" int osuf_skinny_fwd_group(int mode, const float* x, long ldx, const osuf_linear_desc* descs, int n, int total_blocks, int M, int K,
+                                     int in_act, hipStream_t stream) {
+  if (sk_group_bad(x, ldx, M, K, in_act) || !descs || n <= 0 || total_blocks <= 0) return OSUF_EINVAL;
+  if (mode == OSUF_DT_BF16) hipLaunchKernelGGL(skinny_fwd_group_kernel<1>, dim3(total_blocks), dim3(256), 0, stream, x, ldx, descs, n, M, K, in_act);
+  else hipLaunchKernelGGL(skinny_fwd_group_kernel<0>, dim3(total_blocks), dim3(256), 0, stream, x, ldx, descs, n, M, K, in_act);
+  return osuf_launch_status();
+}
+extern "C" int osuf_skinny_dx_group(int mode, const osuf_linear_desc* descs, int n, int total_slices, const float* x, long ldx, float* dx, long lddx,
+                                    int M, int K, int in_act, hipStream_t stream) {
+  if (sk_group_bad(x, ldx, M, K, in_act) || !descs || n <= 0 || total_slices <= 0 || !dx || lddx < K) return OSUF_EINVAL;
+  hipError_t e = hipMemsetAsync(dx, 0, (size_t)M * lddx * sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  const dim3 grid((K + 31) / 32, total_slices);
+  if (mode == OSUF_DT_BF16) hipLaunchKernelGGL(skinny_dx_group_kernel<1>, grid, dim3(256), 0, stream, descs, n, x, ldx, dx, lddx, M, K, in_act);
+  else hipLaunchKernelGGL(skinny_dx_group_kernel<0>, grid, dim3(256), 0, stream, descs, n, x, ldx, dx, lddx, M, K, in_act);
   return osuf_launch_status();
 }

@@ -440,6 +440,68 @@ class SkinnyLinearFn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+class LinearGroupFn(torch.autograd.Function):
+    """[in_act(x) W_i^T + b_i] for linears that share the input x -- the FiLM projections of every conditioned ResidualBlock of a
+    UNet forward (residual.py:104-111,126-131: Sequential(SiLU, Linear) on the same cat(t, c)) -- one launch forward, one launch for
+    dx = sum_i dy_i W_i backward.  Weight gradients: with a Trainer (direct gradient accumulation) film_group() hangs a hook on
+    every output that adds dW_i / db_i into the parameters' .grad the moment that block's backward has produced dy_i -- as early as
+    the per-block form did, which is what the bucketed all-reduce overlaps with; without one they are returned from here."""
+
+    @staticmethod
+    def forward(ctx, x, mode_dtype, in_act, direct, *wb):
+        n = len(wb) // 2
+        ws, bs = wb[:n], wb[n:]
+        x = x.contiguous()
+        ys = ops.skinny_fwd_group(x, ws, bs, mode_dtype, in_act)
+        ctx.save_for_backward(x, *ws)
+        ctx.cfg, ctx.bs = (mode_dtype, in_act, direct, n), bs
+        ctx.set_materialize_grads(False)                    # an output nobody used stays None in backward (no zero tensors)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        x, *ws = ctx.saved_tensors
+        mode_dtype, in_act, direct, n = ctx.cfg
+        dys = [g.contiguous().float() if g is not None else None for g in gouts]
+        dx = ops.skinny_dx_group(dys, ws, x, mode_dtype, in_act) if ctx.needs_input_grad[0] else None
+        dws, dbs = [None] * n, [None] * n
+        if not direct:
+            for i, (dy, w, b) in enumerate(zip(dys, ws, ctx.bs)):
+                if dy is None or not ctx.needs_input_grad[4 + i]:
+                    continue
+                dws[i] = torch.empty(w.shape, dtype=torch.float32, device=w.device)
+                if b is not None and ctx.needs_input_grad[4 + n + i]:
+                    dbs[i] = torch.zeros(b.shape, dtype=torch.float32, device=w.device)
+                ops.skinny_bwd(dy, None, x, w, mode_dtype, in_act, 0, False, dws[i], dbs[i], False)
+        return (dx, None, None, None, *dws, *dbs)
+
+
+def film_group(x: torch.Tensor, linears, mode_dtype: torch.dtype, in_act: int):
+    """-> {id(weight): output} of LinearGroupFn over nn.Linear modules `linears`; see LinearGroupFn for the gradient routing."""
+    ws = tuple(l.weight for l in linears)
+    bs = tuple(l.bias for l in linears)
+    direct = _DIRECT and torch.is_grad_enabled() and all(grad_target(w) is not None for w in ws if w.requires_grad) and \
+        all(b is None or not b.requires_grad or grad_target(b) is not None for b in bs)
+    ys = LinearGroupFn.apply(x, mode_dtype, in_act, direct, *ws, *bs)
+    if direct:
+        xs = x.detach()
+        for y, w, b in zip(ys, ws, bs):
+            if y.requires_grad and w.requires_grad:
+                y.register_hook(_film_dw_hook(xs, w, b, mode_dtype, in_act))
+    return {id(w): y for w, y in zip(ws, ys)}
+
+
+def _film_dw_hook(x, w, b, mode_dtype, in_act):
+    def hook(dy):
+        tb = grad_target(b) if b is not None and b.requires_grad else None
+        ops.skinny_bwd(dy.contiguous().float(), None, x, w, mode_dtype, in_act, 0, False, grad_target(w), tb, True)
+        grad_done(w)
+        if tb is not None:
+            grad_done(b)
+        return None
+    return hook
+
+
 _UNIT_NORM: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
 
 

@@ -113,7 +113,9 @@ class ResidualBlock(nn.Module):
         if self.mlp is not None and (self.has_time_cond or self.has_cond):
             emb = rt.shared_cat(t, c)                      # cat(t, c): one tensor for all blocks of a forward
             lin = self.mlp[1]
-            ss = rt.small_linear(emb, lin.weight, lin.bias, in_act=ops.ACT_SILU)          # (B, 2C): scale | shift
+            ss = rt.film_take(emb, lin)                    # (B, 2C): scale | shift -- from the UNet's one grouped launch, or
+            if ss is None:                                 # (stand-alone block, recomputation, capture) its own
+                ss = rt.small_linear(emb, lin.weight, lin.bias, in_act=ops.ACT_SILU)
         rlink = Fn.ResLink() if torch.is_grad_enabled() and x.requires_grad else None      # residual-path gradient -> block1's dgrad
         h = self.block1.forward_rows(x, ss, rlink)
         h = self.block2.forward_rows(h, None)

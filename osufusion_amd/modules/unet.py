@@ -310,6 +310,7 @@ class UNet(nn.Module):
             UNetBlock(di, do, self.dim_emb, self.dim_emb, i, n_layers, rblocks[i], False, attn_dim_head, attn_heads, attn_kv_heads,
                       attn_context_len // (2 ** (n_layers - i - 1))) for i, (do, di) in enumerate(rev)])
         self._cf = Fn.PackCache()
+        self._film = None                                   # cached list of the FiLM Linears (see _film_linears)
 
     def set_gradient_checkpointing(self, value: bool) -> None:
         """unet.py:452-456: switch reentrant activation checkpointing of every UNetBlock (the reference prints one line per
@@ -351,7 +352,17 @@ class UNet(nn.Module):
         finally:
             rt.clear_shared_cat()                          # the 35 FiLM projections shared one cat(t, c)
 
+    def _film_linears(self):
+        """The Linear of every conditioned ResidualBlock's Sequential(SiLU, Linear), in module order (35 at the headline config)."""
+        if self._film is None:
+            self._film = [m.mlp[1] for m in self.modules() if isinstance(m, ResidualBlock) and m.mlp is not None and isinstance(m.mlp[1], nn.Linear)]
+        return self._film
+
     def _denoise_rows(self, x_rows: torch.Tensor, a_rows: torch.Tensor, t: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+        # every block projects the same cat(t, c): run all the projections now, in one launch (blocks pick theirs up by weight).
+        # Not under reentrant activation checkpointing -- its recomputation runs each block's own projection anyway.
+        if not (self.training and any(getattr(l, "gradient_checkpointing", False) for l in (*self.down_layers, *self.up_layers))):
+            rt.film_prepare(rt.shared_cat(t, c), self._film_linears())
         r = x_rows
         x = x_rows
         skips = []

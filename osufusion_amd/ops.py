@@ -532,6 +532,61 @@ def skinny_bwd(dy: torch.Tensor, y: Optional[torch.Tensor], x: torch.Tensor, w: 
     return dx
 
 
+# osuf_linear_desc (include/osufusion_hip.h), 56 bytes
+LINEAR_DESC = np.dtype([("W", "<u8"), ("bias", "<u8"), ("y", "<u8"), ("dy", "<u8"), ("ldy", "<i8"), ("lddy", "<i8"), ("N", "<i4"), ("block0", "<i4")])
+
+
+def _upload_table(tab: np.ndarray, device) -> torch.Tensor:
+    """Descriptor table -> device without stalling the host: pinned staging (the caching host allocator keeps the block alive
+    until the copy has run) + an asynchronous copy on the current stream."""
+    host = torch.empty(tab.nbytes, dtype=torch.uint8, pin_memory=True)
+    host.numpy()[:] = tab.view(np.uint8).reshape(-1)
+    return host.to(device, non_blocking=True)
+
+
+def skinny_group_ok(x: torch.Tensor, ws) -> bool:
+    """The group kernels' vector-path conditions (include/osufusion_hip.h)."""
+    return (x.dtype == torch.float32 and x.dim() == 2 and x.is_cuda and x.stride(1) == 1 and x.shape[1] % 8 == 0 and x.stride(0) % 4 == 0 and
+            x.data_ptr() % 16 == 0 and all(w.dtype == torch.float32 and w.is_contiguous() and w.shape[0] % 8 == 0 and w.data_ptr() % 16 == 0 and
+                                           w.numel() == w.shape[0] * x.shape[1] for w in ws))
+
+
+def skinny_fwd_group(x: torch.Tensor, ws, bs, mode_dtype: torch.dtype, in_act: int):
+    """[in_act(x) W_i^T + b_i for i] for fp32 master weights (N_i, K[, 1]) that share the input rows x (M, K): one launch."""
+    assert skinny_group_ok(x, ws)
+    M, K = x.shape
+    tab = np.zeros(len(ws), dtype=LINEAR_DESC)
+    ys, blocks = [], 0
+    for j, (w, b) in enumerate(zip(ws, bs)):
+        N = w.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        ys.append(y)
+        tab[j] = (w.data_ptr(), b.data_ptr() if b is not None else 0, y.data_ptr(), 0, N, 0, N, blocks)
+        blocks += -(-N // 32)
+    dev = _upload_table(tab, x.device)
+    call("osuf_skinny_fwd_group", _DT[mode_dtype], _p(x), x.stride(0), dev.data_ptr(), len(ws), blocks, M, K, in_act, _stream())
+    return ys
+
+
+def skinny_dx_group(dys, ws, x: torch.Tensor, mode_dtype: torch.dtype, in_act: int) -> torch.Tensor:
+    """dx = in_act'(x) * sum_i dy_i W_i over the linears of a group (dys[i] None: that output had no gradient)."""
+    M, K = x.shape
+    live = [(dy, w) for dy, w in zip(dys, ws) if dy is not None]
+    dx = torch.empty((M, K), dtype=torch.float32, device=x.device)
+    if not live:
+        return dx.zero_()
+    tab = np.zeros(len(live), dtype=LINEAR_DESC)
+    slices = 0
+    for j, (dy, w) in enumerate(live):
+        N = w.shape[0]
+        assert dy.dtype == torch.float32 and dy.shape == (M, N) and dy.is_contiguous() and dy.data_ptr() % 16 == 0
+        tab[j] = (w.data_ptr(), 0, 0, dy.data_ptr(), 0, N, N, slices)
+        slices += -(-N // 512)
+    dev = _upload_table(tab, x.device)
+    call("osuf_skinny_dx_group", _DT[mode_dtype], dev.data_ptr(), len(live), slices, _p(x), x.stride(0), _p(dx), K, M, K, in_act, _stream())
+    return dx
+
+
 _DKIND = {"same": 0, "down": 1, "up": 2}
 
 

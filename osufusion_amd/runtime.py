@@ -120,6 +120,36 @@ def shared_cat(t: Optional[torch.Tensor], c: Optional[torch.Tensor]) -> torch.Te
 
 def clear_shared_cat() -> None:
     _CAT_MEMO[0] = _CAT_MEMO[1] = _CAT_MEMO[2] = _CAT_MEMO[3] = _CAT_MEMO[4] = None
+    film_clear()
+
+
+_FILM_MEMO = [None, None]                                  # [the embedding the group ran on, {id(weight): output}]
+
+
+def film_prepare(emb: torch.Tensor, linears) -> bool:
+    """Run the FiLM projections Sequential(SiLU, Linear) of `linears` on the shared embedding `emb` (= shared_cat(t, c)) in one launch
+    and park the outputs for film_take().  Skipped (-> False: every block then runs its own small_linear) when the group kernels'
+    conditions do not hold, under hipGraph capture (the descriptor table is uploaded per call) and for non-fp32 masters."""
+    _FILM_MEMO[0] = _FILM_MEMO[1] = None
+    if not linears or not emb.is_cuda or torch.cuda.is_current_stream_capturing():
+        return False
+    ws = [l.weight for l in linears]
+    x = emb.float().contiguous()
+    if any(w.dtype != torch.float32 for w in ws) or not ops.skinny_group_ok(x, ws):
+        return False
+    _FILM_MEMO[0], _FILM_MEMO[1] = emb, Fn.film_group(x, linears, compute_dtype(ws[0].dtype), ops.ACT_SILU)
+    return True
+
+
+def film_take(emb: torch.Tensor, lin) -> Optional[torch.Tensor]:
+    """The parked output of film_prepare for this Linear, if the group ran on this very embedding tensor."""
+    if _FILM_MEMO[1] is None or _FILM_MEMO[0] is not emb:
+        return None
+    return _FILM_MEMO[1].pop(id(lin.weight), None)
+
+
+def film_clear() -> None:
+    _FILM_MEMO[0] = _FILM_MEMO[1] = None
 
 
 def small_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], in_act: int = 0, out_act: int = 0) -> torch.Tensor:

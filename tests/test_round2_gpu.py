@@ -323,3 +323,35 @@ def test_grouped_weight_pack_equals_per_weight_pack(golden_dir, dt):
         assert changed >= len(jobs) // 2                                # the optimizer did move the weights the table re-read
     finally:
         Fn.enable_direct_grads(False)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_linear_group_equals_per_linear_kernels(dt):
+    """osuf_skinny_fwd_group / osuf_skinny_dx_group (the 35 FiLM projections of a UNet forward in one launch, residual.py:104-111)
+    against the per-linear kernels: outputs bit-equal (same tile body), dx = the sum of the per-linear dx up to the order of the
+    fp32 adds, weight / bias gradients through autograd equal to SkinnyLinearFn's."""
+    torch.manual_seed(3)
+    M, K = 32, 2048
+    Ns = [512, 1536, 1024, 2048, 520, 8]
+    x = (torch.randn(M, K, device=DEV) * 0.7).requires_grad_()
+    lins = [torch.nn.Linear(K, N).to(DEV) for N in Ns]
+    outs = Fn.film_group(x, lins, dt, ops.ACT_SILU)
+    ys = [outs[id(l.weight)] for l in lins]
+    gs = [torch.randn(M, N, device=DEV) for N in Ns]
+    gs[4] = None                                                          # one output without a gradient
+    torch.autograd.backward([y for y, g in zip(ys, gs) if g is not None], [g for g in gs if g is not None])
+    dx_group, dws = x.grad.clone(), [l.weight.grad.clone() if l.weight.grad is not None else None for l in lins]
+    dbs = [l.bias.grad.clone() if l.bias.grad is not None else None for l in lins]
+    x.grad = None
+    for l in lins:
+        l.weight.grad = l.bias.grad = None
+    refs = [Fn.SkinnyLinearFn.apply(x, l.weight, l.bias, dt, ops.ACT_SILU, 0) for l in lins]
+    for y, r in zip(ys, refs):
+        assert torch.equal(y, r)
+    torch.autograd.backward([r for r, g in zip(refs, gs) if g is not None], [g for g in gs if g is not None])
+    assert rell2(dx_group, x.grad) < 1e-6
+    for i, l in enumerate(lins):
+        if gs[i] is None:
+            assert dws[i] is None and l.weight.grad is None
+        else:
+            assert torch.equal(dws[i], l.weight.grad) and torch.equal(dbs[i], l.bias.grad)
