@@ -154,11 +154,39 @@ class EffWeight:
 # of a 300 ms step).  The reducer is told explicitly when a parameter's gradient is complete.
 _DIRECT = False
 _GRAD_DONE_CB = None
+_GRAD_COMPLETE_CB = None
+_PENDING_USES: Dict[int, int] = {}     # id(param) -> forward uses whose backward hook has not run yet (see grad_use / grad_used)
 
 
-def enable_direct_grads(flag: bool, done_callback=None) -> None:
-    global _DIRECT, _GRAD_DONE_CB
-    _DIRECT, _GRAD_DONE_CB = bool(flag), done_callback
+def enable_direct_grads(flag: bool, done_callback=None, complete_callback=None) -> None:
+    """complete_callback(p): the gradient of p is COMPLETE for this backward.  Only for parameters that are deliberately kept out of the
+    autograd graph (no AccumulateGrad node, hence no post-accumulate hook): the grouped FiLM projections, whose weight gradients are
+    written by tensor hooks (film_group)."""
+    global _DIRECT, _GRAD_DONE_CB, _GRAD_COMPLETE_CB
+    _DIRECT, _GRAD_DONE_CB, _GRAD_COMPLETE_CB = bool(flag), done_callback, complete_callback
+    _PENDING_USES.clear()
+
+
+def grad_use(p: torch.Tensor) -> None:
+    """A forward used p outside the autograd graph; its gradient is complete when every such use has reported grad_used."""
+    _PENDING_USES[id(p)] = _PENDING_USES.get(id(p), 0) + 1
+
+
+def grad_used(p: torch.Tensor) -> None:
+    left = _PENDING_USES.get(id(p), 1) - 1
+    if left > 0:
+        _PENDING_USES[id(p)] = left
+        return
+    _PENDING_USES.pop(id(p), None)
+    if _GRAD_DONE_CB is not None:
+        _GRAD_DONE_CB(p)
+    if _GRAD_COMPLETE_CB is not None:
+        _GRAD_COMPLETE_CB(p)
+
+
+def reset_grad_uses() -> None:
+    """End of a backward (GradReducer.finish): uses whose hook never ran (an output nobody differentiated) must not linger."""
+    _PENDING_USES.clear()
 
 
 def grad_target(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -443,9 +471,9 @@ class SkinnyLinearFn(torch.autograd.Function):
 class LinearGroupFn(torch.autograd.Function):
     """[in_act(x) W_i^T + b_i] for linears that share the input x -- the FiLM projections of every conditioned ResidualBlock of a
     UNet forward (residual.py:104-111,126-131: Sequential(SiLU, Linear) on the same cat(t, c)) -- one launch forward, one launch for
-    dx = sum_i dy_i W_i backward.  Weight gradients: with a Trainer (direct gradient accumulation) film_group() hangs a hook on
-    every output that adds dW_i / db_i into the parameters' .grad the moment that block's backward has produced dy_i -- as early as
-    the per-block form did, which is what the bucketed all-reduce overlaps with; without one they are returned from here."""
+    dx = sum_i dy_i W_i backward.  Weight gradients: with a Trainer (direct gradient accumulation) every output passes through a
+    _FilmTapFn in its block, which adds dW_i / db_i into the parameters' .grad the moment that block's backward has produced dy_i
+    -- as early as the per-block form did, which is what the bucketed all-reduce overlaps with; without one they are returned here."""
 
     @staticmethod
     def forward(ctx, x, mode_dtype, in_act, direct, *wb):
@@ -477,29 +505,57 @@ class LinearGroupFn(torch.autograd.Function):
 
 
 def film_group(x: torch.Tensor, linears, mode_dtype: torch.dtype, in_act: int):
-    """-> {id(weight): output} of LinearGroupFn over nn.Linear modules `linears`; see LinearGroupFn for the gradient routing."""
+    """-> {id(weight): (output, tap info)} of LinearGroupFn over nn.Linear modules `linears`; blocks take theirs through film_tap().
+    With a Trainer the weights enter the node DETACHED: they have no AccumulateGrad node (whose post-accumulate hook would only fire
+    after the group node, at the very end of the backward); _FilmTapFn writes dW_i / db_i into .grad and reports the parameter
+    complete (grad_used) when its block's backward has produced dy_i."""
     ws = tuple(l.weight for l in linears)
     bs = tuple(l.bias for l in linears)
-    direct = _DIRECT and torch.is_grad_enabled() and all(grad_target(w) is not None for w in ws if w.requires_grad) and \
+    direct = _DIRECT and _GRAD_COMPLETE_CB is not None and torch.is_grad_enabled() and \
+        all(not w.requires_grad or grad_target(w) is not None for w in ws) and \
         all(b is None or not b.requires_grad or grad_target(b) is not None for b in bs)
-    ys = LinearGroupFn.apply(x, mode_dtype, in_act, direct, *ws, *bs)
     if direct:
+        ys = LinearGroupFn.apply(x, mode_dtype, in_act, True, *(w.detach() for w in ws), *(None if b is None else b.detach() for b in bs))
         xs = x.detach()
-        for y, w, b in zip(ys, ws, bs):
-            if y.requires_grad and w.requires_grad:
-                y.register_hook(_film_dw_hook(xs, w, b, mode_dtype, in_act))
-    return {id(w): y for w, y in zip(ws, ys)}
+        return {id(w): (y, (xs, w, b, mode_dtype, in_act) if y.requires_grad and w.requires_grad else None) for w, b, y in zip(ws, bs, ys)}
+    ys = LinearGroupFn.apply(x, mode_dtype, in_act, False, *ws, *bs)
+    return {id(w): (y, None) for w, y in zip(ws, ys)}
 
 
-def _film_dw_hook(x, w, b, mode_dtype, in_act):
-    def hook(dy):
+def film_tap(entry):
+    """One parked output of film_group, taken by its block.  With a Trainer it passes through _FilmTapFn HERE, in the block's forward:
+    autograd runs ready nodes in reverse creation order, so a tap created next to its block runs right after that block's backward
+    (created up front with the group, all 35 would run last, together)."""
+    y, info = entry
+    if info is None:
+        return y
+    xs, w, b, mode_dtype, in_act = info
+    grad_use(w)
+    if b is not None and b.requires_grad:
+        grad_use(b)
+    return _FilmTapFn.apply(y, xs, (w, b), mode_dtype, in_act)        # (w, b) as a tuple: not autograd inputs
+
+
+class _FilmTapFn(torch.autograd.Function):
+    """Identity on one output of LinearGroupFn.  Its backward runs the moment the consuming block has produced dy_i (a tensor hook
+    on the group's output would only run with the group node itself, after ALL blocks): it adds dW_i / db_i into the parameters'
+    .grad and reports them complete, then hands dy_i on to the group node for dx."""
+
+    @staticmethod
+    def forward(ctx, y, x, wb, mode_dtype, in_act):
+        ctx.refs = (x, wb[0], wb[1], mode_dtype, in_act)
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b, mode_dtype, in_act = ctx.refs
+        dy = dy.contiguous().float()
         tb = grad_target(b) if b is not None and b.requires_grad else None
-        ops.skinny_bwd(dy.contiguous().float(), None, x, w, mode_dtype, in_act, 0, False, grad_target(w), tb, True)
-        grad_done(w)
+        ops.skinny_bwd(dy, None, x, w.detach(), mode_dtype, in_act, 0, False, grad_target(w), tb, True)
+        grad_used(w)
         if tb is not None:
-            grad_done(b)
-        return None
-    return hook
+            grad_used(b)
+        return dy, None, None, None, None
 
 
 _UNIT_NORM: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor]] = {}

@@ -145,7 +145,8 @@ def film_take(emb: torch.Tensor, lin) -> Optional[torch.Tensor]:
     """The parked output of film_prepare for this Linear, if the group ran on this very embedding tensor."""
     if _FILM_MEMO[1] is None or _FILM_MEMO[0] is not emb:
         return None
-    return _FILM_MEMO[1].pop(id(lin.weight), None)
+    entry = _FILM_MEMO[1].pop(id(lin.weight), None)
+    return None if entry is None else Fn.film_tap(entry)
 
 
 def film_clear() -> None:

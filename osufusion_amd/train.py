@@ -159,6 +159,11 @@ class GradReducer:
         if idx is not None:
             self._ready(idx)
 
+    def param_complete(self, p) -> None:
+        """functional.grad_used: the gradient of a parameter that is kept out of the autograd graph (so has no post-accumulate hook) is
+        complete -- every forward use has written its share.  Same effect as the hook."""
+        self._hook(p)
+
     def _ready(self, idx: int) -> None:
         if self._fresh:                                    # first report after a finish(): a new backward (begin() is optional)
             self._open()
@@ -193,6 +198,7 @@ class GradReducer:
         self.handles = []
         self.pending = list(self.expected)
         self._done, self._fresh = set(self._seen), True
+        Fn.reset_grad_uses()
 
     def observed_order(self) -> List[int]:
         """Parameter indices in the order the last finished backward completed them; never-reported ones follow, in place."""
@@ -302,7 +308,7 @@ class Trainer:
         if self.reducer.enabled:                            # identical replicas (guard; inits are already deterministic)
             dist.broadcast(self.flat.data, src=0)
         Fn.bump_weight_epoch()
-        Fn.enable_direct_grads(True, self.reducer.param_ready)
+        Fn.enable_direct_grads(True, self.reducer.param_ready, self.reducer.param_complete)
 
     def step(self, x, a, c, noise=None, timesteps=None, orig_len=None):
         """One micro-batch.  Returns (loss, total_norm): total_norm is the device scalar of the clipped step's gradient norm on

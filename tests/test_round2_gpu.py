@@ -336,7 +336,7 @@ def test_linear_group_equals_per_linear_kernels(dt):
     x = (torch.randn(M, K, device=DEV) * 0.7).requires_grad_()
     lins = [torch.nn.Linear(K, N).to(DEV) for N in Ns]
     outs = Fn.film_group(x, lins, dt, ops.ACT_SILU)
-    ys = [outs[id(l.weight)] for l in lins]
+    ys = [Fn.film_tap(outs[id(l.weight)]) for l in lins]
     gs = [torch.randn(M, N, device=DEV) for N in Ns]
     gs[4] = None                                                          # one output without a gradient
     torch.autograd.backward([y for y, g in zip(ys, gs) if g is not None], [g for g in gs if g is not None])
@@ -355,3 +355,34 @@ def test_linear_group_equals_per_linear_kernels(dt):
             assert dws[i] is None and l.weight.grad is None
         else:
             assert torch.equal(dws[i], l.weight.grad) and torch.equal(dbs[i], l.bias.grad)
+
+
+def test_grouped_film_weights_complete_with_their_blocks(golden_dir):
+    """The grouped FiLM projections must not delay gradient completion (what the bucketed all-reduce overlaps with): each
+    `mlp.1.weight` reports complete right after its own block's backward, not with the group node at the end of the backward."""
+    from osufusion_amd.pattern import synth_inputs
+    from osufusion_amd.train import Trainer
+    x, a, c, t, noise = (torch.from_numpy(v).to(DEV) for v in synth_inputs("film", 2, 256))
+    try:
+        _, _, m = _build_model("unet_tiny", golden_dir)
+        tr = Trainer(m, lr=1e-3, compute_dtype=torch.float32, reorder_buckets=False)
+        calls = []
+        orig = ops.call
+        ops.call = lambda name, *args, **kw: (calls.append(name), orig(name, *args, **kw))[1]
+        try:
+            tr.step(x, a, c, noise, t)
+        finally:
+            ops.call = orig
+        assert calls.count("osuf_skinny_fwd_group") == 1 and calls.count("osuf_skinny_dx_group") == 1
+        names = {id(p): k for k, p in m.named_parameters()}
+        order = [names[id(tr.flat.params[i])] for i in tr.reducer.order_log]
+        assert len(order) == len(tr.flat.params) == len(set(order))          # every parameter reported exactly once
+        ranks = [i for i, k in enumerate(order) if k.endswith(".mlp.1.weight")]
+        assert len(ranks) >= 8
+        assert ranks[0] < len(order) // 8 and ranks[len(ranks) // 2] < 3 * len(order) // 4, ranks
+        # each FiLM weight completes right behind the first conv of its own block (block1's backward produces the FiLM gradient)
+        for k in (k for k in order if k.endswith(".mlp.1.weight")):
+            blk = k[: -len(".mlp.1.weight")]
+            assert 0 < order.index(k) - order.index(blk + ".block1.proj.weight") <= 6, (k, order.index(k), order.index(blk + ".block1.proj.weight"))
+    finally:
+        Fn.enable_direct_grads(False)
