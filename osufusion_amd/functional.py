@@ -864,31 +864,35 @@ class AttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, nw, nb, wq, wkv, wo, bo, cache, heads, dim_head, scale_base, aq=None, akv=None,
-                qa=None, qb=None, qm=None, kva=None, kvb=None, kvm=None):
+                qa=None, qb=None, qm=None, kva=None, kvb=None, kvm=None, kv_heads=1, base=None):
+        # kv_heads = G > 1 (grouped-query attention, unet.py:132-135): the caller hands wq with its head blocks in GROUP-MAJOR order
+        # (heads g*H/G .. share K/V head g) and wo with its input columns permuted alike (modules/unet.py Attention._forward_gqa);
+        # base = (to_q.weight, to_out.weight): the parameters those two views derive from -- what the pack cache must version on
         B, N, C = x.shape
-        H, D = heads, dim_head
+        H, D, G = heads, dim_head, kv_heads
         dt = x.dtype
         xn, mr = ops.ln_fwd(x, nw, nb)
-        wqkv = AttentionFn._qkv_packs(cache, dt, wq, wkv, aq, akv)[0]
-        qkv = ops.gemm_nt(xn, wqkv, None, out_shape=(B, N, (H + 2) * D))
+        wqkv = AttentionFn._qkv_packs(cache, dt, wq, wkv, aq, akv, base)[0]
+        qkv = ops.gemm_nt(xn, wqkv, None, out_shape=(B, N, (H + 2 * G) * D))
         cos, sin = rope_tables(N, D, scale_base, x.device)
-        qkv_r = ops.rope_cast(qkv, cos, sin, N, H + 1, H + 2, D)                # rotate q heads and k; cast v
+        qkv_r = ops.rope_cast(qkv, cos, sin, N, H + G, H + 2 * G, D)            # rotate q heads and k heads; cast v
         del qkv
         scale = D ** -0.5
-        o, lse = ops.mqa_fwd(qkv_r, B, N, H, D, dt, scale)
-        wpo = cache.packs(("po", dt), (wo,), wo, "same", dt)[0]
+        o, lse = ops.mqa_fwd(qkv_r, B, N, H, D, dt, scale, kv_heads=G)
+        wpo = cache.packs(("po", dt), (wo,) if base is None else (base[1],), wo, "same", dt)[0]
         out = ops.gemm_nt(o, wpo, bo, residual=xn, out_shape=x.shape)
+        ctx.base = base
         ctx.save_for_backward(x, nw, mr, xn, wq, wkv, wo, qkv_r, o, lse)
-        ctx.cache, ctx.geom = cache, (H, D, scale_base, scale)
+        ctx.cache, ctx.geom = cache, (H, D, scale_base, scale, G)
         ctx.nb, ctx.bo = nb, bo
         ctx.aq, ctx.akv = aq, akv
         return out
 
     @staticmethod
-    def _qkv_packs(cache, dt, wq, wkv, aq, akv):
+    def _qkv_packs(cache, dt, wq, wkv, aq, akv, base=None):
         """Stacked (q | kv) projection operands; adapted halves use their effective weight."""
         if aq is None and akv is None:
-            return cache.packs(("qkv", dt), (wq, wkv), (wq, wkv), "same", dt)
+            return cache.packs(("qkv", dt), (wq, wkv) if base is None else (base[0], wkv), (wq, wkv), "same", dt)
         ws = (aq.effective()[0] if aq is not None else wq, akv.effective()[0] if akv is not None else wkv)
         params = (wq, wkv) + (aq.params if aq is not None else ()) + (akv.params if akv is not None else ())
         return cache.packs(("qkv_dora", dt), params, ws, "same", dt)
@@ -901,7 +905,7 @@ class AttentionFn(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, dout):
         x, nw, mr, xn, wq, wkv, wo, qkv_r, o, lse = ctx.saved_tensors
-        H, D, scale_base, scale = ctx.geom
+        H, D, scale_base, scale, G = ctx.geom
         cache = ctx.cache
         need = ctx.needs_input_grad
         B, N, C = x.shape
@@ -910,23 +914,24 @@ class AttentionFn(torch.autograd.Function):
         # to_out
         dwo = conv_wgrad(dout, o, wo, "same") if need[5] else None
         dbo = _bias_grad(dout, ctx.bo) if need[6] else None
-        wdo = cache.packs(("po", dt), (wo,), wo, "same", dt)[1]
-        if ops.FUSE_ROWDOT:
+        wdo = cache.packs(("po", dt), (wo,) if ctx.base is None else (ctx.base[1],), wo, "same", dt)[1]
+        if ops.FUSE_ROWDOT and G == 1:
             do, delta = ops.gemm_nt_rowdot(dout, wdo, o, N, H)                   # dO and sum_d dO * O from one epilogue
         else:
             do, delta = ops.gemm_nt(dout, wdo, None, out_shape=o.shape), None
         do16 = ops.cast_rows(do, torch.bfloat16)                                 # SDPA backward runs in bf16 (attention.py:101)
         # attention + rope
         cos, sin = rope_tables(N, D, scale_base, x.device)
-        dqkv = ops.mqa_bwd(qkv_r, o, do16, lse, B, N, H, D, scale, dt, cos, sin, variant=ops.ATTN_BWD_DEFAULT, delta=delta)  # RoPE transpose + cast ride the kernels' epilogues
+        dqkv = ops.mqa_bwd(qkv_r, o, do16, lse, B, N, H, D, scale, dt, cos, sin, variant=ops.ATTN_BWD_DEFAULT, delta=delta,
+                           kv_heads=G)                                           # RoPE transpose + cast ride the kernels' epilogues
         # to_q / to_kv
         dwq = conv_wgrad(dqkv[..., : H * D], xn, wq, "same") if need[3] else None
         dwkv = conv_wgrad(dqkv[..., H * D:], xn, wkv, "same") if need[4] else None
         aq, akv = ctx.aq, ctx.akv
-        packs = AttentionFn._qkv_packs(cache, dt, wq, wkv, aq, akv)
+        packs = AttentionFn._qkv_packs(cache, dt, wq, wkv, aq, akv, ctx.base)
         gq = gkv = (None, None, None)
         if (aq is not None and any(need[13:16])) or (akv is not None and any(need[16:19])):
-            qkv = ops.gemm_nt(xn, packs[0], None, out_shape=(B, N, (H + 2) * D))     # pre-RoPE projections again (for d magnitude)
+            qkv = ops.gemm_nt(xn, packs[0], None, out_shape=(B, N, (H + 2 * G) * D))  # pre-RoPE projections again (for d magnitude)
             if aq is not None:
                 gq = adapter_grads(aq, dqkv[..., : H * D], xn, qkv[..., : H * D], None, "same", cache)
             if akv is not None:
@@ -940,7 +945,7 @@ class AttentionFn(torch.autograd.Function):
             grad_done(nw); grad_done(ctx.nb)
             dnw = dnb = None
         return (dx, dnw if need[1] else None, dnb if need[2] else None, dwq, dwkv, dwo, dbo, None, None, None, None, None, None,
-                *gq, *gkv)
+                *gq, *gkv, None, None)
 
 
 class RowsFromNCLFn(torch.autograd.Function):

@@ -50,8 +50,12 @@ class Attend(nn.Module):
         B, H, N, D = q.shape
         if D != 64:
             raise NotImplementedError("HIP attention kernel is built for head_dim 64")
-        if k.shape[1] != 1 and not (torch.equal(k[:, :1].expand_as(k), k) and torch.equal(v[:, :1].expand_as(v), v)):
-            raise NotImplementedError("HIP attention kernel is MQA (one K/V head, as the UNet builds it)")
-        qkv = torch.cat([q.permute(0, 2, 1, 3).reshape(B, N, H * D), k[:, 0], v[:, 0]], dim=-1).to(torch.bfloat16).contiguous()
-        o, _ = ops.mqa_fwd(qkv, B, N, H, D, torch.bfloat16, D ** -0.5)
+        if k.shape[1] not in (1, H) or v.shape[1] != k.shape[1]:
+            raise ValueError(f"k / v must carry 1 or {H} heads (got {k.shape[1]} / {v.shape[1]})")
+        G = k.shape[1]
+        if G != 1 and torch.equal(k[:, :1].expand_as(k), k) and torch.equal(v[:, :1].expand_as(v), v):
+            G, k, v = 1, k[:, :1], v[:, :1]                 # one K/V head repeated (what the UNet's Attention hands over): one launch
+        rows = lambda t: t.permute(0, 2, 1, 3).reshape(B, N, t.shape[1] * D)
+        qkv = torch.cat([rows(q), rows(k), rows(v)], dim=-1).to(torch.bfloat16).contiguous()
+        o, _ = ops.mqa_fwd(qkv, B, N, H, D, torch.bfloat16, D ** -0.5, kv_heads=G)   # G = H: every query head has its own K/V head
         return o.view(B, N, H, D).permute(0, 2, 1, 3).to(v.dtype)

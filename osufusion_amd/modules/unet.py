@@ -161,9 +161,13 @@ class Attention(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         rt.require_gpu(x)
-        if self.kv_heads != 1 or self.dim_head != 64:
-            raise NotImplementedError(f"HIP attention is MQA with head_dim 64 (got kv_heads={self.kv_heads}, dim_head={self.dim_head})")
+        if self.dim_head != 64:
+            raise NotImplementedError(f"the HIP attention kernels are built for head_dim 64 (got dim_head={self.dim_head})")
+        if self.heads % self.kv_heads:
+            raise ValueError(f"heads ({self.heads}) must be a multiple of kv_heads ({self.kv_heads})")
         x = rt.cast_rows(x.contiguous(), rt.compute_dtype(self.to_q.weight.dtype))
+        if self.kv_heads != 1:
+            return self._forward_gqa(x)
         extra = ()
         if hasattr(self.to_q, "adapter_inputs") or hasattr(self.to_kv, "adapter_inputs"):                # lora_layers.LoraLinear
             none4 = (None, None, None, None)
@@ -173,6 +177,23 @@ class Attention(nn.Module):
         with scope("Attention"):                           # unet.py:144
             return Fn.AttentionFn.apply(x, self.norm.weight, self.norm.bias, self.to_q.weight, self.to_kv.weight, self.to_out.weight,
                                         self.to_out.bias, self._cache, self.heads, self.dim_head, self.context_len, *extra)
+
+
+    def _forward_gqa(self, x: torch.Tensor) -> torch.Tensor:
+        """kv_heads = G > 1 (unet.py:132-135: `repeat(t, "b h n d -> b (r h) n d")`, i.e. query head j reads K/V head j mod G).  The
+        kernels take one K/V head per launch, so the query heads are regrouped GROUP-MAJOR -- heads {g, g + G, g + 2G, ...} become one
+        contiguous block next to "their" K/V head -- by permuting the head blocks of to_q's rows and of to_out's input columns (views
+        of the parameters: autograd carries the gradients back through the permutation), and AttentionFn runs G launches per pass."""
+        if hasattr(self.to_q, "adapter_inputs") or hasattr(self.to_kv, "adapter_inputs"):
+            raise NotImplementedError("LoRA / DoRA adapters on a grouped-query Attention (kv_heads > 1) have no HIP path")
+        H, G, D = self.heads, self.kv_heads, self.dim_head
+        r, C = H // G, self.to_q.weight.shape[1]
+        wq = self.to_q.weight.view(r, G, D, C).permute(1, 0, 2, 3).reshape(H * D, C)
+        wo = self.to_out.weight.view(-1, r, G, D).permute(0, 2, 1, 3).reshape(-1, H * D)
+        with scope("Attention"):                           # unet.py:144
+            return Fn.AttentionFn.apply(x, self.norm.weight, self.norm.bias, wq, self.to_kv.weight, wo, self.to_out.bias, self._cache,
+                                        H, D, self.context_len, None, None, None, None, None, None, None, None, G,
+                                        (self.to_q.weight, self.to_out.weight))
 
 
 class FeedForward(nn.Sequential):

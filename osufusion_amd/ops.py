@@ -380,15 +380,20 @@ def rope_bwd(dqkv32: torch.Tensor, out_dtype: torch.dtype, cos, sin, N: int, n_r
     return out
 
 
-def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.dtype, scale: float):
-    """qkv: bf16 rows [B*N][(H+2)*D] (q heads | k | v).  Returns o rows [B*N][H*D] and lse2 [B][H][N]."""
+def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.dtype, scale: float, kv_heads: int = 1):
+    """qkv: bf16 rows [B*N][(H+2G)*D] (q heads | G k heads | G v heads).  Returns o rows [B*N][H*D] and lse2 [B][H][N].
+    G = kv_heads > 1 (grouped-query attention, unet.py:135): the q heads are laid out GROUP-MAJOR -- heads g*H/G .. (g+1)*H/G - 1
+    share K/V head g -- and every group is one launch of the one-K/V-head kernels on its column block; lse2 is then [G][B][H/G][N]."""
     M, W, ld = _rows(qkv)
-    assert qkv.dtype == torch.bfloat16 and W == (H + 2) * D
+    G = kv_heads
+    assert qkv.dtype == torch.bfloat16 and W == (H + 2 * G) * D and H % G == 0
+    r = H // G
     o = torch.empty((B, N, H * D), dtype=out_dtype, device=qkv.device)
-    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
-    base = qkv.data_ptr()
-    call("osuf_mqa_fwd", base, ld, base + 2 * H * D, ld, base + 2 * (H + 1) * D, ld, _p(o), H * D, _DT[out_dtype], _p(lse), B, H, N, D,
-         scale, _stream(), meta=N)
+    lse = torch.empty((B, H, N) if G == 1 else (G, B, r, N), dtype=torch.float32, device=qkv.device)
+    base, eo = qkv.data_ptr(), o.element_size()
+    for g in range(G):
+        call("osuf_mqa_fwd", base + 2 * g * r * D, ld, base + 2 * (H + g) * D, ld, base + 2 * (H + G + g) * D, ld, o.data_ptr() + eo * g * r * D,
+             H * D, _DT[out_dtype], lse.data_ptr() + 4 * g * B * r * N, B, r, N, D, scale, _stream(), meta=N)
     return o, lse
 
 
@@ -401,30 +406,38 @@ FUSE_ROWDOT = True      # AttentionFn.backward: sum_d dO * O from the to_out dgr
 
 def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, D: int, scale: float,
             out_dtype: torch.dtype = torch.float32, cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None,
-            variant: int = ATTN_AUTO, qsplit: int = 0, delta: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Gradients laid out like qkv, [B*N][(H+2)*D], in out_dtype.  With the RoPE tables (N, D/2) the q / k gradients are those of
-    the un-rotated projections (the rotation's transpose is applied in the kernels' epilogues)."""
+            variant: int = ATTN_AUTO, qsplit: int = 0, delta: Optional[torch.Tensor] = None, kv_heads: int = 1) -> torch.Tensor:
+    """Gradients laid out like qkv, [B*N][(H+2G)*D], in out_dtype.  With the RoPE tables (N, D/2) the q / k gradients are those of
+    the un-rotated projections (the rotation's transpose is applied in the kernels' epilogues).  kv_heads = G > 1: one launch set
+    per group on its column blocks (see mqa_fwd; lse / delta are [G][B][H/G][N])."""
     M, W, ld = _rows(qkv)
-    assert do.dtype == torch.bfloat16
+    G = kv_heads
+    r = H // G
+    assert do.dtype == torch.bfloat16 and W == (H + 2 * G) * D and (G == 1 or delta is None)
     dqkv = torch.empty((B, N, W), dtype=out_dtype, device=qkv.device)
-    base, gbase, es = qkv.data_ptr(), dqkv.data_ptr(), dqkv.element_size()
-    kp, vp, ldo_ = base + 2 * H * D, base + 2 * (H + 1) * D, _rows(do)[2]
+    es, ldo_, ldo2 = dqkv.element_size(), _rows(do)[2], _rows(o)[2]
     if delta is None:                                      # (B, H, N) sum_d dO * O: given when the to_out dgrad GEMM produced it
-        delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
-        call("osuf_attn_delta", _p(do), ldo_, _p(o), _rows(o)[2], _DT[o.dtype], _p(delta), B, H, N, D, _stream())
-    if variant in (ATTN_FUSED, ATTN_FUSED_SLABS):
-        mode = 1 if variant == ATTN_FUSED_SLABS else 0                            # OSUF_DQ_SLABS / OSUF_DQ_ATOMIC
-        need = _lib.load().osuf_mqa_bwd_fused_workspace_bytes(B, H, N, _DT[out_dtype], qsplit, mode)
-        ws = _workspace(need, qkv.device)
-        call("osuf_mqa_bwd_fused", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase, W, gbase + es * H * D,
-             gbase + es * (H + 1) * D, W, B, H, N, D, scale, _DT[out_dtype], _p(cos), _p(sin), _p(ws), need, qsplit, mode, _stream(), meta=N)
-        return dqkv
-    call("osuf_mqa_bwd_dq", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase, W, B, H, N, D, scale, _DT[out_dtype],
-         _p(cos), _p(sin), variant, _stream(), meta=N)
-    need = _lib.load().osuf_mqa_bwd_dkv_workspace_bytes(B, N, qsplit)  # > 0: short sequence (or forced), the query range is split
-    ws = _workspace(need, qkv.device) if need > 0 else None
-    call("osuf_mqa_bwd_dkv", base, ld, kp, ld, vp, ld, _p(do), ldo_, _p(lse), _p(delta), gbase + es * H * D, gbase + es * (H + 1) * D, W,
-         B, H, N, D, scale, _DT[out_dtype], _p(cos), _p(sin), _p(ws), need if ws is not None else 0, qsplit, variant, _stream(), meta=N)
+        delta = torch.empty((B, H, N) if G == 1 else (G, B, r, N), dtype=torch.float32, device=qkv.device)
+        for g in range(G):
+            call("osuf_attn_delta", do.data_ptr() + 2 * g * r * D, ldo_, o.data_ptr() + o.element_size() * g * r * D, ldo2, _DT[o.dtype],
+                 delta.data_ptr() + 4 * g * B * r * N, B, r, N, D, _stream())
+    for g in range(G):
+        q_, k_, v_ = qkv.data_ptr() + 2 * g * r * D, qkv.data_ptr() + 2 * (H + g) * D, qkv.data_ptr() + 2 * (H + G + g) * D
+        dq_, dk_, dv_ = dqkv.data_ptr() + es * g * r * D, dqkv.data_ptr() + es * (H + g) * D, dqkv.data_ptr() + es * (H + G + g) * D
+        do_, lse_, delta_ = do.data_ptr() + 2 * g * r * D, lse.data_ptr() + 4 * g * B * r * N, delta.data_ptr() + 4 * g * B * r * N
+        if variant in (ATTN_FUSED, ATTN_FUSED_SLABS):
+            mode = 1 if variant == ATTN_FUSED_SLABS else 0                        # OSUF_DQ_SLABS / OSUF_DQ_ATOMIC
+            need = _lib.load().osuf_mqa_bwd_fused_workspace_bytes(B, r, N, _DT[out_dtype], qsplit, mode)
+            ws = _workspace(need, qkv.device)
+            call("osuf_mqa_bwd_fused", q_, ld, k_, ld, v_, ld, do_, ldo_, lse_, delta_, dq_, W, dk_, dv_, W, B, r, N, D, scale, _DT[out_dtype],
+                 _p(cos), _p(sin), _p(ws), need, qsplit, mode, _stream(), meta=N)
+            continue
+        call("osuf_mqa_bwd_dq", q_, ld, k_, ld, v_, ld, do_, ldo_, lse_, delta_, dq_, W, B, r, N, D, scale, _DT[out_dtype],
+             _p(cos), _p(sin), variant, _stream(), meta=N)
+        need = _lib.load().osuf_mqa_bwd_dkv_workspace_bytes(B, N, qsplit)  # > 0: short sequence (or forced), the query range is split
+        ws = _workspace(need, qkv.device) if need > 0 else None
+        call("osuf_mqa_bwd_dkv", q_, ld, k_, ld, v_, ld, do_, ldo_, lse_, delta_, dk_, dv_, W,
+             B, r, N, D, scale, _DT[out_dtype], _p(cos), _p(sin), _p(ws), need if ws is not None else 0, qsplit, variant, _stream(), meta=N)
     return dqkv
 
 

@@ -122,6 +122,9 @@ def module_cases() -> None:
     m = shim_attend(ref_unet.Attention(96, 64, 4, 1, context_len=256))
     load_pattern(m)
     save("mod_attention", y=m(xt))
+    m = shim_attend(ref_unet.Attention(96, 64, 4, 2, context_len=256))         # grouped-query: 4 query heads on 2 K/V heads (unet.py:132-135)
+    load_pattern(m)
+    save("mod_attention_gqa", y=m(xt))
     xc = T(uniform_pm("mod/xc", (B, 96, 128), 1.0))
     m = shim_attend(ref_unet.TransformerBlock(96, attn_dim_head=64, attn_heads=4, attn_kv_heads=1, attn_context_len=256))
     load_pattern(m)

@@ -348,6 +348,38 @@ def test_transformer_block_vs_oracle(dtype, tol):
         assert rell2(v.grad, p["m." + k].grad) < gtol, k
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-3), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("heads,kv_heads", [(4, 2), (4, 4), (6, 3)])
+def test_grouped_query_attention_vs_oracle(dtype, tol, heads, kv_heads):
+    """Attention with kv_heads > 1 (unet.py:132-135: query head j reads K/V head j mod kv_heads): forward and every gradient -- through
+    the head-block permutation of to_q / to_out and one launch set per K/V head -- against the oracle's autograd; optimizer-style
+    in-place weight updates must invalidate the packed operands of the permuted views."""
+    C, N = 96, 136
+    cfg = O.UNetConfig(dim_h=C, attn_dim_head=64, attn_heads=heads, attn_kv_heads=kv_heads)
+    att = load_pattern(U.Attention(C, 64, heads, kv_heads, context_len=256).to(DEV))
+    for rep in range(2):
+        p = {"m." + k: v.detach().cpu().clone().requires_grad_() for k, v in att.state_dict().items()}
+        x = torch.randn(B, N, C).to(dtype).float()
+        xr = x.clone().requires_grad_()
+        ref = O.attention(p, "m", xr, cfg, 256, O.Numerics("bf16" if dtype == torch.bfloat16 else "fp32"))
+        rows = x.to(DEV).to(dtype).clone().requires_grad_()
+        with oa.forced_compute_dtype(dtype):
+            out = att(rows)
+        assert relmax(out.float(), ref) < tol
+        g = torch.randn(B, N, C).to(dtype).float()
+        ref.backward(g)
+        for v in att.parameters():
+            v.grad = None
+        out.backward(g.to(DEV).to(dtype))
+        gtol = 2e-2 if dtype == torch.float32 else 6e-2                   # SDPA backward is bf16 on both sides
+        assert rell2(rows.grad.float(), xr.grad) < gtol
+        for k, v in att.named_parameters():
+            assert rell2(v.grad, p["m." + k].grad) < gtol, k
+        with torch.no_grad():                                             # what torch.optim does: the second pass must see new weights
+            for v in att.parameters():
+                v.add_(0.05 * torch.randn_like(v))
+
+
 def test_scheduler_and_optimizer_kernels():
     x = torch.randn(4, 6, 100, device=DEV)
     n = torch.randn_like(x)
@@ -442,6 +474,8 @@ def test_modules_vs_golden(golden_dir):
         assert relmax(m(torch.tensor([0, 1, 17, 500, 999], device=DEV)), G(golden_dir, "mod_sinusoidal")["y"]) < 1e-4
         m = load_pattern(U.Attention(96, 64, 4, 1, context_len=256).to(DEV))
         assert relmax(m(T(uniform_pm("mod/xt", (B, 128, 96), 1.0))), G(golden_dir, "mod_attention")["y"]) < TOL
+        m = load_pattern(U.Attention(96, 64, 4, 2, context_len=256).to(DEV))               # grouped-query (kv_heads = 2)
+        assert relmax(m(T(uniform_pm("mod/xt", (B, 128, 96), 1.0))), G(golden_dir, "mod_attention_gqa")["y"]) < TOL
         m = load_pattern(U.TransformerBlock(96, attn_dim_head=64, attn_heads=4, attn_kv_heads=1, attn_context_len=256).to(DEV))
         assert relmax(m(T(uniform_pm("mod/xc", (B, 96, 128), 1.0))), G(golden_dir, "mod_transformer")["y"]) < TOL
         te, ce = T(uniform_pm("mod/te", (B, 64), 1.0)), T(uniform_pm("mod/ce", (B, 64), 1.0))

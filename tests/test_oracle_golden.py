@@ -118,6 +118,9 @@ def test_attention_transformer(golden_dir):
     # Attention case was generated from a standalone Attention module: keys are local (no "attn." prefix)
     pa = P([(k[len("attn."):], s) for k, s in strip(O._transformer_shapes("m", 96, cfg), "m") if k.startswith("attn.")])
     close(O.attention(pa, "m", xt, cfg, 256, NM), G(golden_dir, "mod_attention")["y"], 2e-5)
+    cfg2 = O.UNetConfig(dim_h=96, attn_dim_head=64, attn_heads=4, attn_kv_heads=2)          # grouped-query: head j reads K/V head j mod 2
+    pg = P([(k[len("attn."):], s) for k, s in strip(O._transformer_shapes("m", 96, cfg2), "m") if k.startswith("attn.")])
+    close(O.attention(pg, "m", xt, cfg2, 256, NM), G(golden_dir, "mod_attention_gqa")["y"], 2e-5)
     xc = T(uniform_pm("mod/xc", (B, 96, 128), 1.0))
     close(O.transformer_block(p, "m", xc, cfg, 256, NM), G(golden_dir, "mod_transformer")["y"], 2e-5)
 

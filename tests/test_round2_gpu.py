@@ -165,6 +165,10 @@ def test_attend_module_vs_sdpa(N):
     want = F.scaled_dot_product_attention(qb, kb, vb).to(torch.bfloat16).float()
     assert rell2(got, want) < 5e-3 and relmax(got, want) < 1.5e-2
     assert torch.equal(got, Attend()(q, k1, v1))                                         # un-repeated single K/V head: same kernel
+    kh, vh = torch.randn(Bn, H, N, D, device=DEV), torch.randn(Bn, H, N, D, device=DEV)  # a K/V head of its own per query head
+    got = Attend()(q, kh, vh)
+    want = F.scaled_dot_product_attention(qb, kh.to(torch.bfloat16).float().cpu(), vh.to(torch.bfloat16).float().cpu()).to(torch.bfloat16).float()
+    assert rell2(got, want) < 5e-3 and relmax(got, want) < 1.5e-2
     with pytest.raises(NotImplementedError):
         Attend()(q, k, v, attn_mask=torch.ones(N, N, device=DEV, dtype=torch.bool))
 
