@@ -388,6 +388,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
 // ds_read_b128 -- both AT the CU's limits.  This geometry needs 32 B/clk and 192 B/clk.  One workgroup per CU.
 // Epilogue: each wave transposes its own 64x64 sub-tiles through a private 16 KiB LDS slice (no block barrier).
 // ---------------------------------------------------------------------------------------------------------
+// The 256^2 kernel's output rows leave with the non-temporal hint: a launch writes 67-300 MB that nothing re-reads before the launch
+// ends, and as plain stores those lines displaced the A / W panels the other workgroups of the XCD were still reading from L2
+// (tools/bench_gemm.py, same box: q|kv 256 -> 1152 168 -> 150 us, to_out 94 -> 86, ff2 53 -> 47, k3 convs +1-4 %).
+__device__ __forceinline__ void store8_nt(bf16_t* p, const float (&v)[8]) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+  __builtin_nontemporal_store(r, reinterpret_cast<u32x4*>(p));
+}
+__device__ __forceinline__ void store8_nt(float* p, const float (&v)[8]) {
+  f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+  __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(p));
+  __builtin_nontemporal_store(b, reinterpret_cast<f32x4*>(p + 4));
+}
+
 static constexpr int kBig = 256;
 static constexpr int kBigStage = 2 * kBig * 128;        // 64 KiB: A 256 rows + B 256 rows, 128 B of K each
 
@@ -524,7 +539,7 @@ __device__ __forceinline__ void gemm_big_epilogue_impl(const GemmArgs& g, f32x16
             for (int e = 0; e < 8; ++e) v[e] += rr[e];
           }
         }
-        store8(C + (long)m * g.ldc + n, v);
+        store8_nt(C + (long)m * g.ldc + n, v);   // streaming: see store8_nt
         if (g.stats) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) { float q = ElemTraits<T>::rnd(v[e]); s1 += q; s2 += q * q; }
