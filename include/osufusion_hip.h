@@ -9,7 +9,7 @@
  *   - plain device pointers + sizes + hipStream_t; no allocation, no host sync, graph-capturable.  Nothing is kept between
  *     calls except the one-time hipFuncSetAttribute registration of kernels that need > 64 KiB of LDS.  Kernel variants are
  *     chosen per call (`variant` arguments); the GEMM launchers additionally honour the documented A/B environment switches
- *     OSUF_GEMM_* (read on every call, never cached) -- measurement aids, not configuration;
+ *     OSUF_GEMM_* / OSUF_TN_* (read on every call, never cached) -- measurement aids, not configuration;
  *   - return 0 on success, <0 for an argument error (-1 invalid, -2 unsupported), >0 = hipError_t of the launch;
  *   - activations are channels-last rows [B*L][C] ("rows"), C contiguous, row stride `ld*` in ELEMENTS;
  *   - dtype: 0 = fp32 storage (exact-f32 MFMA), 1 = bf16 storage (bf16 MFMA, fp32 accumulate);
