@@ -84,6 +84,10 @@ int osuf_gn_stats(int dtype, const void* y, long ldy, double* partial, float* me
 long osuf_gn_stats_workspace_bytes(int M, int C, int L);
 int osuf_gn_apply_fwd(int dtype, const void* y, long ldy, void* h, long ldh, const float* mean_rstd, const float* gamma,
                       const float* beta, const float* scale_shift, int M, int C, int L, hipStream_t stream);
+/* osuf_gn_finalize + osuf_gn_apply_fwd in one launch: stats[b] = raw (sum, sum of squares) over count = L*C elements; the kernel
+ * finalises them itself and also writes (mean, rstd) to mr_out[B][2] (needed again by osuf_gn_bwd). */
+int osuf_gn_apply_fwd_stats(int dtype, const void* y, long ldy, void* h, long ldh, const double* stats, long count, float* mr_out,
+                            const float* gamma, const float* beta, const float* ss, int M, int C, int L, hipStream_t stream);
 /* T1234 [B][4][C] fp32 zeroed scratch; S [B][2] scratch; dss [B][2C] (may be NULL); dgamma/dbeta accumulated into; dbias (may be
  * NULL): gradient of the bias of the conv that produced y (= column sums of dy, residual.py:77 `self.proj`), accumulated into;
  * dyy (may be NULL, needs dbias): column sums of dy*y -- the DoRA magnitude gradient's numerator (lora_layers.py:86-90).

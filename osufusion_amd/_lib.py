@@ -26,6 +26,7 @@ SIGNATURES = {
     "osuf_colsum": [I, P, L, I, I, P, P],
     "osuf_gn_finalize": [P, P, I, L, P],
     "osuf_gn_apply_fwd": [I, P, L, P, L, P, P, P, P, I, I, I, P],
+    "osuf_gn_apply_fwd_stats": [I, P, L, P, L, P, L, P, P, P, P, I, I, I, P],
     "osuf_gn_bwd": [I, P, L, P, L, P, L, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     "osuf_ln_fwd": [I, P, L, P, L, P, P, P, I, I, P],
     "osuf_ln_bwd": [I, P, L, P, L, P, L, P, P, P, P, I, I, P],

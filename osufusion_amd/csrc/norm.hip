@@ -81,7 +81,8 @@ __global__ void gn_finalize_parts_kernel(const double* part, float* mr, int B, i
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const T* y, long ldy, T* h, long ldh, const float* mr,
                                                            const float* gamma, const float* beta, const float* ss,
-                                                           int M, int C, int L, int rows_per_block) {
+                                                           int M, int C, int L, int rows_per_block,
+                                                           const double* stats, double inv_count, float* mr_out) {
   // grid (row blocks of one sample, sample): a thread keeps ONE 8-channel chunk and walks rows, so gamma / beta / scale / shift /
   // mean / rstd are loaded once per thread and no index division runs per element (the flat idx / chunks, m / L form spent more
   // VALU on 64-bit divisions and operand reloads than on the normalisation itself)
@@ -91,7 +92,17 @@ __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const T* y, long ldy,
   const int ch = threadIdx.x % cg.cp, rl = threadIdx.x / cg.cp;
   if (rl >= cg.rp) return;
   const int c = ch * 8;
-  const float mean = mr[2 * b], rstd = mr[2 * b + 1];
+  float mean, rstd;
+  if (stats) {                                             // (sum, sum of squares) of the sample, as the producing GEMM's epilogue left them:
+    const double m1 = stats[2 * b] * inv_count;            // finalised here (what osuf_gn_finalize computes: 102 tiny launches per step less)
+    double var = stats[2 * b + 1] * inv_count - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m1;
+    rstd = (float)(1.0 / sqrt(var + (double)kEps));
+    if (blockIdx.x == 0 && threadIdx.x == 0) { mr_out[2 * b] = mean; mr_out[2 * b + 1] = rstd; }   // kept for the backward
+  } else {
+    mean = mr[2 * b]; rstd = mr[2 * b + 1];
+  }
   float g[8], bt[8], k[8], sh[8];
   load8(gamma + c, g);
   load8(beta + c, bt);
@@ -729,16 +740,29 @@ extern "C" int osuf_gn_stats(int dtype, const void* y, long ldy, double* partial
   return osuf_launch_status();
 }
 
-extern "C" int osuf_gn_apply_fwd(int dtype, const void* y, long ldy, void* h, long ldh, const float* mr, const float* gamma,
-                                 const float* beta, const float* ss, int M, int C, int L, hipStream_t stream) {
+static int gn_apply_fwd_launch(int dtype, const void* y, long ldy, void* h, long ldh, const float* mr, const float* gamma, const float* beta,
+                               const float* ss, int M, int C, int L, const double* stats, long count, float* mr_out, hipStream_t stream) {
   if (bad_c(C) || M <= 0 || L <= 0 || M % L || ldy % 8 || ldh % 8) return OSUF_EINVAL;
   {
     const int rp = 256 / (C / 8);
     const int rpb = rp * 8;                                // 8 rows per thread
     DISPATCH_T(dtype, hipLaunchKernelGGL(gn_apply_fwd_kernel<T>, dim3((L + rpb - 1) / rpb, M / L), dim3(256), 0, stream,
-                                         (const T*)y, ldy, (T*)h, ldh, mr, gamma, beta, ss, M, C, L, rpb));
+                                         (const T*)y, ldy, (T*)h, ldh, mr, gamma, beta, ss, M, C, L, rpb, stats,
+                                         stats ? 1.0 / (double)count : 0.0, mr_out));
   }
   return osuf_launch_status();
+}
+extern "C" int osuf_gn_apply_fwd(int dtype, const void* y, long ldy, void* h, long ldh, const float* mr, const float* gamma,
+                                 const float* beta, const float* ss, int M, int C, int L, hipStream_t stream) {
+  if (!mr) return OSUF_EINVAL;
+  return gn_apply_fwd_launch(dtype, y, ldy, h, ldh, mr, gamma, beta, ss, M, C, L, nullptr, 0, nullptr, stream);
+}
+/* The same with the statistics still raw: stats[b] = (sum, sum of squares) of sample b over `count` = L * C elements (the GEMM
+ * epilogue's output); osuf_gn_finalize's arithmetic runs in the kernel and (mean, rstd) is also written to mr_out[B][2]. */
+extern "C" int osuf_gn_apply_fwd_stats(int dtype, const void* y, long ldy, void* h, long ldh, const double* stats, long count, float* mr_out,
+                                       const float* gamma, const float* beta, const float* ss, int M, int C, int L, hipStream_t stream) {
+  if (!stats || !mr_out || count <= 0) return OSUF_EINVAL;
+  return gn_apply_fwd_launch(dtype, y, ldy, h, ldh, nullptr, gamma, beta, ss, M, C, L, stats, count, mr_out, stream);
 }
 
 // T1234: [B][4][C] fp32, must be zero on entry.  dss may be null (no FiLM).  dgamma / dbeta / dbias (the latter optional: gradient

@@ -588,12 +588,15 @@ class BlockFn(torch.autograd.Function):
             y = conv_forward(x, weff, bias, cache, "same", ("dora", *adapter.params), stats=stats)
         else:
             y = conv_forward(x, w, bias, cache, "same", None, stats=stats)
+        ssc = ss.contiguous() if ss is not None else None
         if ctx.identity_norm:
             mr = torch.tensor([0.0, 1.0], dtype=torch.float32, device=x.device).repeat(B, 1)
+            h = ops.gn_apply(y, mr, gamma, beta, ssc, L)
+        elif repro:
+            mr = ops.gn_stats(y, L)
+            h = ops.gn_apply(y, mr, gamma, beta, ssc, L)
         else:
-            mr = ops.gn_stats(y, L) if repro else ops.gn_finalize(stats, L * C)
-        ssc = ss.contiguous() if ss is not None else None
-        h = ops.gn_apply(y, mr, gamma, beta, ssc, L)
+            h, mr = ops.gn_apply_from_stats(y, stats, gamma, beta, ssc, L)       # the epilogue's raw sums are finalised in the kernel
         ctx.save_for_backward(x, w, y, mr, gamma, beta, ssc if ssc is not None else mr)
         ctx.cache, ctx.has_ss, ctx.adapter = cache, ss is not None, adapter
         ctx.bias_ref, ctx.reslink = bias, reslink

@@ -267,6 +267,15 @@ def gn_stats(y: torch.Tensor, L: int) -> torch.Tensor:
     return mr
 
 
+def gn_apply_from_stats(y: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ss: Optional[torch.Tensor], L: int):
+    """gn_finalize + gn_apply in one launch: stats (B, 2) fp64 raw sums from the GEMM epilogue -> (h, mean_rstd (B, 2))."""
+    M, C, ld = _rows(y)
+    h = torch.empty(y.shape, dtype=y.dtype, device=y.device)
+    mr = torch.empty((M // L, 2), dtype=torch.float32, device=y.device)
+    call("osuf_gn_apply_fwd_stats", dt_of(y), _p(y), ld, _p(h), C, _p(stats), L * C, _p(mr), _p(gamma), _p(beta), _p(ss), M, C, L, _stream())
+    return h, mr
+
+
 def gn_apply(y: torch.Tensor, mr: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ss: Optional[torch.Tensor], L: int) -> torch.Tensor:
     M, C, ld = _rows(y)
     h = torch.empty(y.shape, dtype=y.dtype, device=y.device)
