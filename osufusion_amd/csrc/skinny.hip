@@ -344,7 +344,8 @@ extern "C" int osuf_skinny_bwd(int mode, const float* dy, long lddy, const float
     int nsplit = (256 + ktiles - 1) / ktiles;                 // about one workgroup per CU
     const int max_split = (N + 127) / 128;                    // but at least 128 rows of W per slice
     if (nsplit > max_split) nsplit = max_split;
-    if (nsplit < 1) nsplit = 1;
+    if ((long)N * K <= 64 * 1024) nsplit = 1;                 // <= 256 KB of weights (the GlobalContext MLPs): one slice per strip -- plain
+    if (nsplit < 1) nsplit = 1;                               // stores, no memset launch, and the walk over N is 4 steps at most
     int nps = (N + nsplit - 1) / nsplit;
     nps = (nps + 63) / 64 * 64;                                // whole 64-row steps (4 waves x 16) and 8-float alignment of the slices
     nsplit = (N + nps - 1) / nps;
