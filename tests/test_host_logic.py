@@ -317,6 +317,31 @@ def test_capi_ctypes_signatures_match_header():
         assert _lib.SIGNATURES[name] == want, name
 
 
+def test_capi_descriptor_structs_match_their_numpy_layouts():
+    """osuf_pack_desc / osuf_linear_desc (device tables of the grouped entry points): the header's field order and C layout (LP64:
+    8-byte pointers and longs, 4-byte ints, natural alignment) against the numpy structured dtypes ops.py fills them through."""
+    src = (ROOT / "include" / "osufusion_hip.h").read_text()
+    for cname, dt in (("osuf_pack_desc", ops.PACK_DESC), ("osuf_linear_desc", ops.LINEAR_DESC)):
+        body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname + ";", src, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields, off = [], 0
+        for decl in (d.strip() for d in body.split(";") if d.strip()):
+            size = 8 if ("*" in decl or decl.startswith("long")) else 4
+            assert "*" in decl or decl.split()[0] in ("long", "int", "const"), decl
+            names = [n.strip().lstrip("*") for n in decl.replace("*", " * ").split("*")[-1].split(",")] if "*" in decl else \
+                    [n.strip() for n in decl.split(None, 1)[1].split(",")]
+            for n in names:
+                off = (off + size - 1) // size * size
+                fields.append((n, off, size))
+                off += size
+        total = (off + 7) // 8 * 8
+        assert total == dt.itemsize, (cname, total, dt.itemsize)
+        assert len(fields) == len(dt.names)
+        alias = {"f_tapstride": "f_ts", "d_tapstride": "d_ts"}
+        for (n, o, sz), dn in zip(fields, dt.names):
+            assert alias.get(n, n) == dn and dt.fields[dn][1] == o and dt.fields[dn][0].itemsize == sz, (cname, n, dn, o)
+
+
 def test_capi_library_loads_and_reports_version():
     lib = _lib.load()
     assert lib.osuf_version() == 1          # host-only entry point: no GPU needed
