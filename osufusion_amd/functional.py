@@ -63,17 +63,21 @@ class PackCache:
                     off += w.shape[0]
                 pair = (fwd, dgr)
         job = None
-        if all(_plain_master(w) for w in ws):
+        if all(_plain_master(w, params) for w in ws):
             job = _PackJob(self, key, tuple(params), tuple(ws), kind, dt, pair)
             _PACK_JOBS[(id(self), key)] = job
         self._d[key] = (ver, pair, job)
         return pair
 
 
-def _plain_master(w) -> bool:
-    """A weight the grouped refresh can re-read in place: an fp32, contiguous leaf parameter (not an adapter's effective weight,
-    not a tensor derived from parameters such as a merged stem)."""
-    return (isinstance(w, torch.Tensor) and w.is_leaf and w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda)
+def _plain_master(w, params=()) -> bool:
+    """A weight the grouped refresh can re-read in place: an fp32, contiguous nn.Parameter that IS one of the cache entry's source
+    parameters (not an adapter's effective weight, not a tensor derived from parameters such as a merged stem, `Parallel`'s
+    c3 + pad(c1), the padded `final_conv` or a GQA-permuted view).  `is_leaf` must not decide this: under no_grad / inference_mode
+    (reentrant activation checkpointing, `sample()` between two optimizer steps) every derived tensor is a leaf too, and a job
+    registered on such a temporary would re-pack from its stale copy after the next optimizer step."""
+    return (isinstance(w, torch.nn.Parameter) and any(w is p for p in params) and w.dtype == torch.float32
+            and w.is_contiguous() and w.is_cuda)
 
 
 class _PackJob:

@@ -142,10 +142,13 @@ def film_prepare(emb: torch.Tensor, linears) -> bool:
 
 
 def film_take(emb: torch.Tensor, lin) -> Optional[torch.Tensor]:
-    """The parked output of film_prepare for this Linear, if the group ran on this very embedding tensor."""
+    """The parked output of film_prepare for this Linear, if the group ran on this very embedding tensor.  The entry stays parked: a
+    ResidualBlock applied twice in one forward takes a fresh tap per use (film_tap use-counts the weight, so its gradient is
+    reported complete once, after the last use -- a second use falling back to small_linear on the attached weight would report
+    it a second time through its AccumulateGrad hook)."""
     if _FILM_MEMO[1] is None or _FILM_MEMO[0] is not emb:
         return None
-    entry = _FILM_MEMO[1].pop(id(lin.weight), None)
+    entry = _FILM_MEMO[1].get(id(lin.weight))
     return None if entry is None else Fn.film_tap(entry)
 
 

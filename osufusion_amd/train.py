@@ -8,7 +8,8 @@ MI355X-first choices (nothing here mirrors accelerate/DDP's object model):
     asynchronously, overlapping the rest of backward; the flat layout follows the OBSERVED completion order of the first
     backward, so buckets complete front to back; xGMI is point-to-point so buckets are large (64 MiB default) -- a few big
     rings, not many small ones.  (Not yet run on more than one physical GPU: the round's box has one; covered by 2-rank
-    gloo tests on CPU and on one GPU.)
+    gloo tests on CPU and on one GPU.)  The layout is agreed across ranks: rank 0's observed order is broadcast and a
+    fingerprint of (name, offset, size) is compared on every rank before the first positional all-reduce over a new layout.
   * no host sync in the step: the clip coefficient and the 1/world averaging are a device scalar read by the AdamW kernel.
 """
 from __future__ import annotations
@@ -109,6 +110,8 @@ class GradReducer:
         self.direct_reports = 0
         self._done = set()
         self._fresh = True                                 # the next completion report opens a new backward
+        self._explicit = False                             # begin() was called for the backward in progress
+        self.duplicate_reports = 0                         # second completion reports of one parameter inside one begin()..finish()
         self.rebuild()
 
     def rebuild(self) -> None:
@@ -140,8 +143,24 @@ class GradReducer:
 
     def begin(self, sync: bool = True) -> None:
         """Start of a backward: sync=False = gradient-accumulation micro-step without communication."""
+        if self.handles:                                   # a previous backward died between launch and finish(): drain it first
+            self.abort()
         self.sync = sync
         self._open()
+        self._explicit = True
+
+    def abort(self) -> None:
+        """A forward / backward raised after buckets were launched: wait for what is on the wire and forget the half-done backward,
+        so the next begin() starts clean (the caller zeroes the gradients: they hold a mix of reduced and local sums)."""
+        for h in self.handles:
+            try:
+                h.wait()
+            except Exception:                              # noqa: BLE001 -- the collective itself failed: nothing left to wait for
+                pass
+        self.handles = []
+        self.pending = list(self.expected)
+        self._seen, self._fresh, self._explicit = set(), True, False
+        Fn.reset_grad_uses()
 
     def _open(self) -> None:
         self._seen = set()
@@ -167,6 +186,16 @@ class GradReducer:
     def _ready(self, idx: int) -> None:
         if self._fresh:                                    # first report after a finish(): a new backward (begin() is optional)
             self._open()
+        if idx in self._seen and self._explicit:
+            # Between begin() and finish() a second report is a DUPLICATE (a parameter that reaches the reducer both through its
+            # AccumulateGrad hook and through functional.grad_used), never a new backward: do not reset the bookkeeping.  It is
+            # harmless while the parameter's bucket is still waiting for others and an error once that bucket is on the wire.
+            self.duplicate_reports += 1
+            if self.enabled and self.sync and self.overlap and self.bucket_of[idx] in self.fired_early:
+                who = self.names.get(id(self.flat.params[idx]), f"#{idx}")
+                raise RuntimeError(f"parameter {who} reported its gradient complete twice in one backward and its bucket was already "
+                                   "all-reduced after the first report: the second contribution would be lost")
+            return
         if idx in self._seen:                              # one AccumulateGrad node per parameter: a second hook = a new backward
             if self.enabled and self.sync and self.overlap and self.handles:
                 who = self.names.get(id(self.flat.params[idx]), f"#{idx}")
@@ -197,7 +226,7 @@ class GradReducer:
                 h.wait()
         self.handles = []
         self.pending = list(self.expected)
-        self._done, self._fresh = set(self._seen), True
+        self._done, self._fresh, self._explicit = set(self._seen), True, False
         Fn.reset_grad_uses()
 
     def observed_order(self) -> List[int]:
@@ -305,8 +334,10 @@ class Trainer:
         self.micro = 0                                      # micro-batches accumulated since the last optimizer step
         self._reorder_pending = reorder_buckets
         self.arena = ops.ZeroArena(self.flat.data.device) if self.flat.data.is_cuda else None
+        self.order_disagreements = 0
         if self.reducer.enabled:                            # identical replicas (guard; inits are already deterministic)
             dist.broadcast(self.flat.data, src=0)
+            self.check_layout_agreement()
         Fn.bump_weight_epoch()
         Fn.enable_direct_grads(True, self.reducer.param_ready, self.reducer.param_complete)
 
@@ -328,6 +359,12 @@ class Trainer:
                 else:
                     loss = self.model.loss_with(x, a, c, noise, timesteps, orig_len)
                 loss.backward()
+        except BaseException:
+            # buckets of the dead backward may be on the wire and the flat gradient holds a partial sum: drain, and restart the
+            # accumulation window (trainer.py:296-299 skips the batch on an AssertionError and goes on with the next one)
+            self.reducer.abort()
+            self.micro = 0
+            raise
         finally:
             ops.set_zero_arena(None)
         self.reducer.finish()
@@ -346,10 +383,52 @@ class Trainer:
         """Re-lay the flat buffers (parameters, gradients, Adam moments) out in the gradient-completion order of the last
         backward and rebuild the buckets over the new layout."""
         order = self.reducer.observed_order()
+        if self.reducer.enabled:
+            order = self._agree_on_order(order)
         if order != list(range(len(order))):
             self.opt.exp_avg, self.opt.exp_avg_sq = self.flat.reorder(order, (self.opt.exp_avg, self.opt.exp_avg_sq))
             self.reducer.rebuild()
             Fn.bump_weight_epoch()                          # parameter storage moved: cached operand packs key on data_ptr
+        self.check_layout_agreement()
+
+    def _comm_device(self) -> torch.device:
+        """Where small control tensors of a collective must live: the GPU for RCCL, the host for gloo."""
+        backend = str(dist.get_backend(self.reducer.group)).lower()
+        return self.flat.data.device if "nccl" in backend else torch.device("cpu")
+
+    def _agree_on_order(self, order: List[int]) -> List[int]:
+        """Every rank must lay its flat buffers out identically: the bucketed all-reduce is positional.  Rank 0's observed order is
+        broadcast and used everywhere (what torch DDP does with its rebuilt bucket order); a rank whose own backward completed the
+        gradients in another order is counted in `order_disagreements` (it only loses some overlap)."""
+        dev = self._comm_device()
+        t = torch.tensor(order, dtype=torch.int64, device=dev)
+        dist.broadcast(t, src=0, group=self.reducer.group)
+        agreed = [int(v) for v in t.cpu().tolist()]
+        if sorted(agreed) != list(range(len(order))):
+            raise RuntimeError("rank 0 broadcast an order that is not a permutation of this rank's parameters: the ranks hold different models")
+        self.order_disagreements = getattr(self, "order_disagreements", 0) + int(agreed != list(order))
+        return agreed
+
+    def layout_fingerprint(self) -> int:
+        """63-bit hash of (parameter name, offset, numel) in flat order."""
+        import hashlib
+        h = hashlib.sha256()
+        for p, o in zip(self.flat.params, self.flat.offsets):
+            h.update(f"{self.reducer.names.get(id(p), '?')}:{o}:{p.numel()};".encode())
+        return int.from_bytes(h.digest()[:8], "little") >> 1
+
+    def check_layout_agreement(self) -> None:
+        """Raise unless every rank's flat layout (names, offsets, sizes) is the same.  Called after construction and after every
+        re-layout: a silent mismatch would make ranks sum different parameters into each other."""
+        if not self.reducer.enabled:
+            return
+        dev = self._comm_device()
+        mine = torch.tensor([self.layout_fingerprint()], dtype=torch.int64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(self.reducer.world)]
+        dist.all_gather(every, mine, group=self.reducer.group)
+        vals = [int(v.item()) for v in every]
+        if len(set(vals)) != 1:
+            raise RuntimeError(f"flat parameter layouts differ across ranks (fingerprints {vals}): refusing to all-reduce positionally")
 
     # -- checkpoint.pt in the reference's layout (trainer.py:148-203): resumable by either trainer ------------------------
     def state_dict(self, scheduler_state: Optional[dict] = None) -> dict:

@@ -218,3 +218,103 @@ def test_shared_module_and_direct_notifications():
         assert raised
         assert torch.allclose(mine, no_overlap, rtol=1e-6, atol=1e-8)      # both paths: the summed gradient of the shared module
     assert torch.equal(out[0][0], out[1][0])
+
+
+def _worker_order_agreement(rank, world, port, out):
+    """Trainer.apply_observed_order with ranks that observed DIFFERENT completion orders: rank 0's order is broadcast and used by
+    everyone, the layout fingerprints agree afterwards, and a rank that re-lays its buffers out on its own is caught."""
+    from osufusion_amd import functional as Fn
+    from osufusion_amd.train import Trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _model()
+        tr = Trainer(model, lr=1e-3, bucket_mib=0.001, compute_dtype=None, reorder_buckets=False)
+        names = tr.reducer.names
+        x, y = _data()
+        xs, ys = x.chunk(world)[rank], y.chunk(world)[rank]
+        tr.flat.zero_grad()
+        tr.reducer.begin(sync=True)
+        ((model(xs) - ys) ** 2).mean().backward()
+        tr.reducer.finish()
+        rank0_order = list(tr.reducer.order_log)
+        if rank == 1:                                               # this rank "saw" another order (e.g. a data-dependent branch)
+            tr.reducer.order_log = list(reversed(tr.reducer.order_log))
+        before = {names[id(p)]: p.detach().clone() for p in tr.flat.params}
+        init_names = [names[id(p)] for p in tr.flat.params]
+        tr.apply_observed_order()
+        layout = [(names[id(p)], o) for p, o in zip(tr.flat.params, tr.flat.offsets)]
+        assert [n for n, _ in layout] == [init_names[i] for i in rank0_order]      # rank 0's order everywhere
+        for p in tr.flat.params:
+            assert torch.equal(p.detach(), before[names[id(p)]])
+        # a second backward over the agreed layout still averages correctly
+        tr.flat.zero_grad()
+        tr.reducer.begin(sync=True)
+        ((model(xs) - ys) ** 2).mean().backward()
+        tr.reducer.finish()
+        g = {names[id(p)]: p.grad.clone() / world for p in tr.flat.params}
+        # a rank that re-lays out on its own must be caught by the fingerprint check, on every rank
+        if rank == 1:
+            n = len(tr.flat.params)
+            tr.opt.exp_avg, tr.opt.exp_avg_sq = tr.flat.reorder([1, 0] + list(range(2, n)), (tr.opt.exp_avg, tr.opt.exp_avg_sq))
+            tr.reducer.rebuild()
+        caught = False
+        try:
+            tr.check_layout_agreement()
+        except RuntimeError as e:
+            caught = "layouts differ" in str(e)
+        out[rank] = (layout, tr.order_disagreements, g, caught, tr.layout_fingerprint())
+    finally:
+        Fn.enable_direct_grads(False)
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_observed_order_is_agreed_across_ranks():
+    """ADVICE r2 (medium) / torch DDP's rebuilt-bucket broadcast: the bucketed all-reduce is positional over the flat gradient
+    buffer, so ranks that observed different completion orders must still end up with ONE layout (trainer.py:264-269,301)."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_order_agreement, args=(world, _free_port(), out), nprocs=world, join=True)
+    (l0, d0, g0, c0, f0), (l1, d1, g1, c1, f1) = out[0], out[1]
+    assert l0 == l1, "offsets / order differ across ranks after apply_observed_order"
+    assert d0 == 0 and d1 == 1                                      # rank 1's own observation lost against rank 0's
+    model = _model()
+    x, y = _data()
+    ((model(x) - y) ** 2).mean().backward()
+    for n, p in model.named_parameters():
+        assert torch.allclose(g0[n], p.grad, rtol=1e-5, atol=1e-7) and torch.equal(g0[n], g1[n]), n
+    assert c0 and c1 and f0 != f1                                   # the rogue re-layout is refused on both ranks
+
+
+def test_duplicate_completion_reports_and_abort():
+    """ADVICE r2 (low x2): inside begin()..finish() a second completion report of one parameter must not be mistaken for a new
+    backward (it used to reset the bucket bookkeeping mid-backward); a backward that dies leaves the reducer clean for the next."""
+    model = _model()
+    flat = FlatParameters(model, align=4)
+    red = GradReducer(flat, bucket_mib=0.001)
+    x, y = _data()
+    flat.zero_grad()
+    red.begin()
+    ((model(x) - y) ** 2).mean().backward()
+    log = list(red.order_log)
+    red.param_complete(flat.params[0])                              # e.g. a tap callback + the AccumulateGrad hook of one parameter
+    assert red.order_log == log and red.duplicate_reports == 1      # not re-opened, not recorded twice
+    red.finish()
+    assert red.observed_order() == log
+    # implicit mode (no begin()): a repeated hook still means "a new backward"
+    flat.zero_grad()
+    ((model(x) - y) ** 2).mean().backward()
+    ((model(x) - y) ** 2).mean().backward()
+    assert red.order_log == log and red.duplicate_reports == 1
+    red.finish()
+    # abort(): forgets the half-done backward
+    red.begin()
+    red.param_complete(flat.params[1])
+    red.abort()
+    assert red.handles == [] and red._seen == set() and red._fresh
+    red.begin()
+    ((model(x) - y) ** 2).mean().backward()
+    red.finish()
+    assert red.observed_order() == log
