@@ -105,6 +105,12 @@ def test_full_size_one_sample_gradient_vs_oracle(full):
     loss_ref.backward()
     gref = {k: v.grad for k, v in p.items()}
     ref_flat = torch.cat([g.reshape(-1) for g in gref.values()]).double()
+    # The oracle's OWN bf16-autocast emulation on the same sample: its per-parameter distance from its fp32 self is the floor that
+    # bf16 arithmetic (not a kernel defect) puts under every parameter; the HIP bf16 gradients are held to a small multiple of it.
+    for v in p.values():
+        v.grad = None
+    DO.training_loss(p, cfg, xs, as_, cs, ns, ts, cond_drop_prob=0.0, mode="bf16").backward()
+    gorc = {k: v.grad for k, v in p.items()}
     try:
         trainer = Trainer(model, compute_dtype=torch.float32, reorder_buckets=False)
         names = {id(q): n for n, q in model.named_parameters()}
@@ -134,6 +140,27 @@ def test_full_size_one_sample_gradient_vs_oracle(full):
             assert e_loss < tol_loss, (tag, e_loss)
             assert e_flat < tol_flat, (tag, e_flat)
             assert rel_norm.max() < tol_norm_max and rel_norm.median() < tol_norm_med, (tag, rel_norm.max(), rel_norm.median())
+            if mode == torch.bfloat16:
+                # the timed mode against the oracle's bf16 emulation, parameter by parameter
+                orc_flat = torch.cat([gorc[k].reshape(-1) for k in gref]).double()
+                den = {k: max(gref[k].double().norm().item(), floor) for k in gref}
+                d_orc = torch.tensor([(gorc[k].double() - gref[k].double()).norm().item() / den[k] for k in gref])       # oracle bf16 vs oracle fp32
+                d_hip = rel_norm                                                                                          # HIP bf16 vs oracle fp32
+                d_x = torch.tensor([(got[k].double() - gorc[k].double()).norm().item() / den[k] for k in gref])          # HIP bf16 vs oracle bf16
+                ratio = d_hip / d_orc.clamp_min(2e-3)
+                keys = list(gref)
+                iw = int(ratio.argmax())
+                ih = int(d_hip.argmax())
+                report("full_size_gradient_bf16_floor", oracle_bf16_vs_fp32_flat=((orc_flat - ref_flat).norm() / ref_flat.norm()).item(),
+                       hip_bf16_vs_oracle_bf16_flat=((got_flat - orc_flat).norm() / orc_flat.norm()).item(),
+                       oracle_per_param_max=d_orc.max(), oracle_per_param_median=d_orc.median(), hip_per_param_max=d_hip.max(),
+                       hip_vs_oracle_bf16_per_param_max=d_x.max(), hip_vs_oracle_bf16_per_param_median=d_x.median(),
+                       worst_ratio=ratio.max(), worst_ratio_param=keys[iw], hip_worst_param=keys[ih], hip_worst=d_hip[ih],
+                       oracle_at_hip_worst=d_orc[ih], ratio_median=ratio.median())
+                # every parameter's HIP-bf16 error is within 3x the oracle's own bf16-vs-fp32 error on that parameter (floored at 2e-3):
+                # the 0.2 outliers of the table above are parameters on which the reference's autocast is just as far from fp32
+                assert ratio.max() < 3.0, (keys[iw], d_hip[iw].item(), d_orc[iw].item())
+                assert ratio.median() < 1.5, ratio.median()
     finally:
         Fn.enable_direct_grads(False)
 

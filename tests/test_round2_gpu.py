@@ -37,6 +37,22 @@ def _attn_case(Bn, N, H, D=64):
     return qkv, do.to(DEV), o_ref.detach(), qkv32.grad
 
 
+def test_fused_attention_backward_beyond_eight_samples():
+    """B = 9, H = 16, N = 512: the fused sweep places sample b = (qid / nkb) * 8 + xcd (attn.hip), so b >= 8 is a second pass of the
+    block-index map that the B <= 2 cases never reach -- checked against autograd of the fp32 formula like the rest."""
+    Bn, N, H, D = 9, 512, 16, 64
+    qkv, do, o_ref, g_ref = _attn_case(Bn, N, H)
+    o, lse = ops.mqa_fwd(qkv, Bn, N, H, D, torch.bfloat16, D ** -0.5)
+    assert rell2(o.float(), o_ref) < 5e-3
+    for name, variant, qsplit in (("fused", ops.ATTN_FUSED, 0), ("fused-split2", ops.ATTN_FUSED, 2), ("fused-slabs", ops.ATTN_FUSED_SLABS, 0),
+                                  ("auto", ops.ATTN_AUTO, 0)):
+        dqkv = ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5, variant=variant, qsplit=qsplit)
+        for bi in range(Bn):                                               # per sample: a mis-placed sample is an O(1) error on it alone
+            e = rell2(dqkv[bi], g_ref[bi])
+            assert e < 1e-2, (name, bi, e)
+        report(f"attn_bwd/B9_H16_N512/{name}", rel_l2=rell2(dqkv, g_ref))
+
+
 @pytest.mark.parametrize("N", [200, 512, 2048, 4096])
 def test_every_attention_backward_kernel_vs_fp32_autograd(N):
     """N = 2048 / 4096 are the shapes at which the train step picks mqa_bwd_dq_pipe_kernel and the unsplit
