@@ -31,8 +31,11 @@ extern "C" {
 #define OSUF_ATTN_PLAIN 1
 #define OSUF_ATTN_PIPE 2
 /* `dq_mode` of osuf_mqa_bwd_fused: fp32 atomics (default), or per-key-block slabs summed in a fixed order */
-#define OSUF_DQ_ATOMIC 0
+#define OSUF_DQ_ATOMIC 0          /* fp32 atomics; the sweep (256 or 512 keys per workgroup) is picked by shape */
 #define OSUF_DQ_SLABS 1
+#define OSUF_DQ_ATOMIC_256 2      /* force the 8-wave, 256-key sweep */
+#define OSUF_DQ_ATOMIC_512 3      /* force the 4-wave, 512-key sweep (N % 32 == 0, else -2) */
+#define OSUF_DQ_TIMING_512 4      /* the 512-key sweep WITHOUT its atomics: timing only, dq comes back zero */
 
 int osuf_version(void);
 

@@ -1077,6 +1077,290 @@ __global__ __launch_bounds__(512) void mqa_bwd_fused_kernel(AttnArgs a, float* d
 //  iteration for both halves.  Correct, but 9.95 ms per backward at B=32, N=4096 against 7.34 ms for the kernel above: past 256
 //  registers hipcc parks accumulators in AGPRs, and the loop spent 200 of its ~700 instructions on v_accvgpr_read / _mov / _write
 //  moving S, dP between the two halves of the file for the VALU.)
+// ------------------------------------------------------------------------------------------------------
+// Fused backward, 512 keys per workgroup (round 3): the same key-stationary sweep with HALF the dQ atomic bytes -- the float-atomic
+// floor of the 256-key kernel above (B*H*N*64*4 bytes x N/256 at the chip's ~1.3 TB/s: 6.6 ms at B=32, N=4096) is what bounds it.
+// Four waves, ONE per SIMD, each with the whole 512-register file: a wave owns 128 keys = four 32-key tiles, and its dK^T / dV^T
+// accumulators (2 x [64 d][128 keys] fp32 = 256 registers) live in the AGPR half of the file for the whole sweep.  hipcc cannot be
+// left to place them: as soon as a kernel may need AGPRs it selects the AGPR form for EVERY MFMA builtin and then shuttles S / dP
+// through v_accvgpr_* for the VALU (round 2's 4-wave try: 200 of 700 loop instructions; reproduced with a 40-line probe this round).
+// So every MFMA of this kernel is an inline-asm statement that names its register class: "+a" accumulators for dK^T / dV^T (they
+// are touched by nothing else until the epilogue), "+v" for S, dP and the dQ tiles, which the VALU consumes.  What hipcc does not
+// do for an asm MFMA is done by hand (cdna_hip_programming.md 5.7): `s_nop 1` in front of each one (an operand may have been
+// written by the VALU instruction just before it), and a fence statement -- s_nop N with the accumulator as a "+v" operand -- before
+// the first non-MFMA reader of a result (8-pass 32x32x16: 12 wait states; 4-pass 16x16x32: 8).
+// Per (head, 32-query block) pair: S^T / dP^T of the wave's four key tiles (their accumulators start from -lse/c and -delta, staged
+// with the Q / dO tile, so p = exp2(c S') and dS = p dP' need no subtraction), dS rows -> the shared [512 keys][32 queries] image,
+// dV^T / dK^T MFMAs; one barrier; one pair later wave w takes the two 16x16 tiles (both query halves, head-dim columns 16w..16w+15)
+// of dQ[32][64] = dS[32][512] K[512][64] and adds them with float atomics: 8 KiB per pair and workgroup, as above, but for twice the
+// keys.  K fragments are read from the resident K image (S needs its rows, dQ its columns), V fragments stay in 64 VGPRs.
+// Whole-block shapes only (N % 32 == 0: every UNet level); keys past N have zero K / V rows (their dS rows meet zero K rows).
+// ------------------------------------------------------------------------------------------------------
+// dS image of the 512-key sweep: [key][32 queries] bf16, 8-byte chunks xor-swizzled by the key's position INSIDE its 32-key tile only, so
+// that a step of 32 keys is a plain +2048 bytes (an instruction offset): with the 256-key image's swizzle (key ^ key >> 3) every one of the
+// 16 k-steps x 4 reads of the dQ phase needed its own per-lane offset register -- 64 of them, which hipcc spilled to scratch
+__device__ __forceinline__ int ds_img_off512(int key, int qchunk) {
+  return key * 64 + ((qchunk ^ ((key ^ ((key >> 3) & 3)) & 7)) << 3);
+}
+__device__ __forceinline__ void mfma32_agpr(f32x16& acc, const bf16x8 a, const bf16x8 b) {
+  asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma32_vgpr(f32x16& acc, const bf16x8 a, const bf16x8 b) {
+  asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma16_vgpr(f32x4& acc, const bf16x8 a, const bf16x8 b) {
+  asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// results of asm MFMAs become readable by the VALU / stores only after the matrix pipe has written them back
+// (none of these statements is `volatile`: a volatile asm is a barrier for every memory operation in hipcc's scheduling graph, which pinned
+//  each LDS fragment read between two MFMAs -- read, s_waitcnt lgkmcnt(0), MFMA, 32 times over -- and cost 2 ms of 8.8; as pure functions of
+//  their operands they are ordered by data dependences alone: chain -> fence -> reader)
+__device__ __forceinline__ void mfma32_fence(f32x16& acc) { asm("s_nop 11" : "+v"(acc)); }
+__device__ __forceinline__ void mfma16_fence(f32x4& a0, f32x4& a1) { asm("s_nop 7" : "+v"(a0), "+v"(a1)); }
+// the same ordering point where the program order already puts >= 2 MFMAs (64 cycles) between the chain's last MFMA and its reader
+__device__ __forceinline__ void mfma32_fence_short(f32x16& acc) { asm("s_nop 3" : "+v"(acc)); }
+__device__ __forceinline__ void mfma32_fence_agpr(f32x16& acc) { asm("s_nop 15\n\ts_nop 3" : "+a"(acc)); }
+
+// ATOMICS = false: timing-only build of the sweep (dQ tiles are computed and dropped) -- prices the loop without its atomics
+template <bool ATOMICS>
+__global__ __launch_bounds__(256, 1) void mqa_bwd_fused512_kernel(AttnArgs a, float* dq32) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][Q 4K | dO 4K | -lse/c 128 | -delta 128] | K image 64K | [2] dS image 32K
+  constexpr int kStage = 4096 + 4096 + 256;
+  char* kimg = smem + 2 * kStage;
+  char* eimg = kimg + 65536;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int nkb = (a.N + 511) / 512;
+  const int per_split = (int)gridDim.x / a.qsplit;
+  const int part = (int)blockIdx.x / per_split, bid = (int)blockIdx.x - part * per_split;
+  const int xcd = bid & 7, qid = bid >> 3;
+  const int b = (qid / nkb) * 8 + xcd;
+  const int kb = qid % nkb;
+  if (b >= a.B) return;
+  const float c = a.scale * kLog2e;
+  const int nqb = a.N >> 5;
+  const int qb_per = (nqb + a.qsplit - 1) / a.qsplit;
+  const int qb_begin = part * qb_per, qb_end = min(nqb, qb_begin + qb_per);
+  if (qb_begin >= qb_end) return;                                  // uniform per workgroup, before any barrier
+  const int niter = (qb_end - qb_begin) * a.H;
+  const int key0 = kb * 512 + wave * 128;                          // this wave's keys: key0 + 32 t + lr, t = 0..3
+
+  bf16x8 vf[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int key = key0 + t * 32 + lr;
+    const long m = (long)b * a.N + key;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 z = {0u, 0u, 0u, 0u}, z2 = {0u, 0u, 0u, 0u};
+      if (key < a.N) { z = *reinterpret_cast<const u32x4*>(a.k + m * a.ldk + 16 * ks + 8 * lh); z2 = *reinterpret_cast<const u32x4*>(a.v + m * a.ldv + 16 * ks + 8 * lh); }
+      vf[t][ks] = __builtin_bit_cast(bf16x8, z2);
+      *reinterpret_cast<u32x4*>(kimg + tile_off(wave * 128 + t * 32 + lr, (2 * ks + lh) * 16)) = z;   // resident K image (zero rows beyond N)
+    }
+  }
+  f32x16 dk[4][2], dv[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[t][i][r] = 0.f; dv[t][i][r] = 0.f; }
+
+  // stage loader (256 threads): thread -> one 16-B chunk of the Q tile and the same chunk of the dO tile; threads 0..31 / 32..63 the
+  // pair's lse / delta rows, stored as the INITIAL ACCUMULATORS -lse2 / c and -delta.  Branch-free, loads before the iteration's atomics
+  // (see mqa_bwd_fused_kernel).
+  const int lrow = tid >> 3, lchunk = tid & 7;
+  const unsigned qoff = (unsigned)(lrow * (int)a.ldq + lchunk * 8), dooff = (unsigned)(lrow * (int)a.lddo + lchunk * 8);
+  const int lds_dst = tile_off(lrow, lchunk * 16);
+  const float* ssrc = (tid & 32) ? a.delta : a.lse2;
+  const float smul = (tid & 32) ? -1.f : -1.f / c;
+  const int last_pb = qb_end - 1;
+  u32x4 rq, rd; float rs = 0.f;
+  int ih = 0, ipb = qb_begin;                                     // (head, query block) of the next stage to load
+  auto load_stage = [&]() {
+    const int pbc = min(ipb, last_pb);                             // past the end: reload the last block (never consumed)
+    const long row0 = (long)b * a.N + pbc * 32;
+    const bf16_t* qb_ = a.q + row0 * a.ldq + ih * D;               // scalar bases
+    const bf16_t* db_ = a.dout + row0 * a.lddo + ih * D;
+    const float* sb = ssrc + ((long)b * a.H + ih) * a.N + pbc * 32;
+    rq = *reinterpret_cast<const u32x4*>(qb_ + qoff);
+    rd = *reinterpret_cast<const u32x4*>(db_ + dooff);
+    rs = sb[(unsigned)(tid & 31)] * smul;
+    if (++ih == a.H) { ih = 0; ++ipb; }
+  };
+  auto store_stage = [&](int slot) {
+    char* base = smem + slot * kStage;
+    *reinterpret_cast<u32x4*>(base + lds_dst) = rq;
+    *reinterpret_cast<u32x4*>(base + 4096 + lds_dst) = rd;
+    if (tid < 64) reinterpret_cast<float*>(base + 8192)[tid] = rs;
+  };
+
+  // dQ of the pair handled one iteration earlier: this wave's tiles = queries 16 qh .. +15 (qh = 0, 1) x head-dim columns 16 wave .. +15.
+  // Its 16 k-steps (32 keys each: 6 transposed reads, 2 MFMAs) are spread over the four key tiles of the iteration, one k-step per
+  // stage, operands read one stage ahead.
+  const int g4 = lane >> 4, ip = lane & 15, tq = ip >> 2, tp = ip & 3;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const int koff0 = tile_off(8 * g4 + tq, (wave * 16 + 4 * tp) * 2), koff1 = tile_off(8 * g4 + 4 + tq, (wave * 16 + 4 * tp) * 2);
+  // float atomics of a dQ tile pair: accumulator column n = lane & 15 -> d, row m = 4 * (lane >> 4) + r -> query (of its half).  Addresses are
+  // a wave-uniform 64-bit base + a 32-bit per-lane BYTE offset (the saddr form): eight zero-extended 64-bit lane offsets would not fit the file
+  const unsigned aoffb = (unsigned)((4 * g4) * (a.H * D) + wave * 16 + ip) * 4u;
+  const unsigned rowb = (unsigned)(a.H * D) * 4u;
+  auto dq_add = [&](const f32x4& q0, const f32x4& q1, int ph_, int ppb_) {
+    if constexpr (ATOMICS) {
+      char* sb = reinterpret_cast<char*>(dq32 + ((long)b * a.N + ppb_ * 32) * (a.H * D) + ph_ * D);      // scalar
+      unsigned ob = aoffb;
+      asm volatile("" : "+v"(ob));                                  // opaque per call: keeps the eight offsets out of loop-invariant registers
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        atomic_add_f32(reinterpret_cast<float*>(sb + (ob + (unsigned)r * rowb)), q0[r]);
+        atomic_add_f32(reinterpret_cast<float*>(sb + (ob + (unsigned)(16 + r) * rowb)), q1[r]);
+      }
+    } else {
+      asm volatile("" :: "v"(q0), "v"(q1));
+    }
+  };
+  const int eoff[2][2] = {{ds_img_off512(8 * g4 + tq, tp), ds_img_off512(8 * g4 + tq + 4, tp)},
+                          {ds_img_off512(8 * g4 + tq, 4 + tp), ds_img_off512(8 * g4 + tq + 4, 4 + tp)}};
+  struct DqOps { bf16x8 bv, av0, av1; };
+  auto dq_read = [&](const char* ep, int ks) {
+    DqOps o;
+    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(kimg + koff0 + ks * 4096));
+    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(kimg + koff1 + ks * 4096));
+    o.bv = __builtin_bit_cast(bf16x8, (s16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]});
+    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(ep + eoff[0][0] + ks * 2048));
+    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(ep + eoff[0][1] + ks * 2048));
+    o.av0 = __builtin_bit_cast(bf16x8, (s16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]});
+    const s16x4 c0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(ep + eoff[1][0] + ks * 2048));
+    const s16x4 c1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(ep + eoff[1][1] + ks * 2048));
+    o.av1 = __builtin_bit_cast(bf16x8, (s16x8){c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]});
+    return o;
+  };
+#define OSUF_FENCE __builtin_amdgcn_sched_barrier(0)
+
+  const LaneOffs lo(lane);
+  for (int i = tid; i < 32768 / 16; i += 256) reinterpret_cast<u32x4*>(eimg + 32768)[i] = u32x4{0u, 0u, 0u, 0u};
+  load_stage(); store_stage(0);
+  __syncthreads();
+  int ph = 0, ppb = qb_begin;                                      // (head, query block) of the previous iteration's pair
+  int ch = 0, cpb = qb_begin;                                      // ... of the current one
+  for (int it = 0; it < niter; ++it) {
+    const char* qs = smem + (it & 1) * kStage;
+    const char* dos = qs + 4096;
+    const float* ls = reinterpret_cast<const float*>(qs + 8192);
+    char* eb = eimg + (it & 1) * 32768;
+    const char* ep = eimg + ((it + 1) & 1) * 32768;                // the previous pair's dS image (it = 0: zeros -> adds 0.0)
+    load_stage();                                                  // global prefetch of the next pair FIRST (older than this iteration's atomics)
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;                // dQ tiles of the two query halves (one chain each: a dependent
+    auto dq_mma = [&](const DqOps& o) {                            // 16x16x32 issues at the rate of an independent one, and successive
+      mfma16_vgpr(acc0, o.av0, o.bv);                              // k-steps sit a whole stage apart)
+      mfma16_vgpr(acc1, o.av1, o.bv);
+    };
+    bf16x8 qa[4], da[4], kf[4];
+    f32x16 s, dp;
+    auto read_tile_consts = [&]() {                                // the initial accumulators of a key tile's S / dP chains: -lse/c, -delta
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(ls + 8 * g + 4 * lh);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(ls + 32 + 8 * g + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[4 * g + e] = l4[e]; dp[4 * g + e] = d4[e]; }
+      }
+    };
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { qa[ks] = lds_row_frag(qs, lo, ks, 0); da[ks] = lds_row_frag(dos, lo, ks, 0); }
+    read_tile_consts();
+    kf[0] = lds_row_frag(kimg + wave * 4 * 4096, lo, 0, 0); kf[1] = lds_row_frag(kimg + wave * 4 * 4096, lo, 1, 0);
+    DqOps o0 = dq_read(ep, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      // One wave per SIMD: nothing overlaps unless it is interleaved in program order, so every group below pairs MFMAs with the
+      // VALU / LDS work that is independent of them (the first all-MFMAs-then-all-VALU order ran 8.6 ms at N = 4096: the sum of the
+      // matrix, vector and LDS times).  Within a tile: S chain | dP chain beside exp2(c S') | dV beside dS = p dP' | dK beside the next
+      // tile's operand reads; the 8 small dQ MFMAs and their 24 transposed reads are spread over the four stages.
+      bf16x8 trd[2][2], trq[2][2];                                 // transposed dO / Q fragments [s2][dt]
+      bf16x8 pf[2], df[2];
+      DqOps o1;
+      typedef __attribute__((ext_vector_type(4))) float f4;
+      auto exp4 = [&](int r0) {
+#pragma unroll
+        for (int r = r0; r < r0 + 4; ++r) s[r] = fast_exp2(s[r] * c);
+      };
+      auto ds4 = [&](int r0) {
+#pragma unroll
+        for (int r = r0; r < r0 + 4; ++r) dp[r] = s[r] * dp[r];    // (x scale folded into the finishing passes)
+      };
+      auto ds_write2 = [&](int g0) {                               // the dS fragment's words ARE the packed row pieces of the image
+#pragma unroll
+        for (int g = g0; g < g0 + 2; ++g) {
+          u32x2 w2;
+          w2[0] = __builtin_bit_cast(u32x4, df[g >> 1])[2 * (g & 1)];
+          w2[1] = __builtin_bit_cast(u32x4, df[g >> 1])[2 * (g & 1) + 1];
+          *reinterpret_cast<u32x2*>(eb + ds_img_off512(wave * 128 + t * 32 + lr, 2 * g + lh)) = w2;
+        }
+      };
+      // slot = one matrix instruction (or a dQ pair), then the fillers that issue while it executes; OSUF_FENCE pins the order.
+      // Fragment reads sit as late as their consumers allow (two slots ahead or more): the register file is full
+      const char* krow = kimg + (wave * 4 + t) * 4096;
+      OSUF_FENCE;
+      mfma32_vgpr(s, qa[0], kf[0]);                 OSUF_FENCE;  o1 = dq_read(ep, 4 * t + 1); kf[2] = lds_row_frag(krow, lo, 2, 0); kf[3] = lds_row_frag(krow, lo, 3, 0);  OSUF_FENCE;
+      mfma32_vgpr(s, qa[1], kf[1]);                 OSUF_FENCE;  dq_mma(o0);                                                    OSUF_FENCE;   // k-step 4t
+      mfma32_vgpr(s, qa[2], kf[2]);                 OSUF_FENCE;  trd[0][0] = lds_tr_frag(dos, lo, 0, 0); trd[0][1] = lds_tr_frag(dos, lo, 0, 1);   OSUF_FENCE;
+      mfma32_vgpr(s, qa[3], kf[3]);                 OSUF_FENCE;  o0 = dq_read(ep, 4 * t + 2);                                   OSUF_FENCE;
+      mfma32_vgpr(dp, da[0], vf[t][0]);             OSUF_FENCE;  trd[1][0] = lds_tr_frag(dos, lo, 16, 0); trd[1][1] = lds_tr_frag(dos, lo, 16, 1); OSUF_FENCE;
+      mfma32_vgpr(dp, da[1], vf[t][1]);             OSUF_FENCE;
+      mfma32_vgpr(dp, da[2], vf[t][2]);             OSUF_FENCE;  mfma32_fence_short(s); exp4(0);                                OSUF_FENCE;
+      mfma32_vgpr(dp, da[3], vf[t][3]);             OSUF_FENCE;  exp4(4);                                                       OSUF_FENCE;
+      dq_mma(o1);                                   OSUF_FENCE;  exp4(8); pf[0] = acc_to_frag(s, 0);                            OSUF_FENCE;   // k-step 4t+1
+      mfma32_agpr(dv[t][0], trd[0][0], pf[0]);      OSUF_FENCE;  exp4(12);                                                      OSUF_FENCE;
+      mfma32_agpr(dv[t][1], trd[0][1], pf[0]);      OSUF_FENCE;  pf[1] = acc_to_frag(s, 1); mfma32_fence_short(dp); ds4(0);
+                                                                 trq[0][0] = lds_tr_frag(qs, lo, 0, 0); trq[0][1] = lds_tr_frag(qs, lo, 0, 1);     OSUF_FENCE;
+      mfma32_agpr(dv[t][0], trd[1][0], pf[1]);      OSUF_FENCE;  ds4(4); ds4(8);                                                OSUF_FENCE;
+      mfma32_agpr(dv[t][1], trd[1][1], pf[1]);      OSUF_FENCE;  ds4(12); df[0] = acc_to_frag(dp, 0);
+                                                                 trq[1][0] = lds_tr_frag(qs, lo, 16, 0); trq[1][1] = lds_tr_frag(qs, lo, 16, 1);   OSUF_FENCE;
+      mfma32_agpr(dk[t][0], trq[0][0], df[0]);      OSUF_FENCE;  df[1] = acc_to_frag(dp, 1); ds_write2(0);                      OSUF_FENCE;
+      mfma32_agpr(dk[t][1], trq[0][1], df[0]);      OSUF_FENCE;  ds_write2(2); o1 = dq_read(ep, 4 * t + 3);                     OSUF_FENCE;
+      mfma32_agpr(dk[t][0], trq[1][0], df[1]);      OSUF_FENCE;  dq_mma(o0); if (t < 3) read_tile_consts();                     OSUF_FENCE;   // k-step 4t+2
+      mfma32_agpr(dk[t][1], trq[1][1], df[1]);      OSUF_FENCE;  dq_mma(o1);                                                                  // k-step 4t+3
+      if (t < 3) { o0 = dq_read(ep, 4 * t + 4); kf[0] = lds_row_frag(krow + 4096, lo, 0, 0); kf[1] = lds_row_frag(krow + 4096, lo, 1, 0); }
+    }
+    OSUF_FENCE;
+    // the previous pair's dQ tiles: accumulator column n = lane & 15 -> d, row m = 4 * (lane >> 4) + r -> query (of its half)
+    mfma16_fence(acc0, acc1);
+    dq_add(acc0, acc1, ph, ppb);
+    store_stage((it + 1) & 1);                                     // (after the last pair: a stage nobody reads)
+    __syncthreads();
+    ph = ch; ppb = cpb;
+    if (++ch == a.H) { ch = 0; ++cpb; }
+  }
+#undef OSUF_FENCE
+  {                                                                // dQ of the last pair
+    const char* ep = eimg + ((niter - 1) & 1) * 32768;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const DqOps o = dq_read(ep, ks);
+      mfma16_vgpr(acc0, o.av0, o.bv);
+      mfma16_vgpr(acc1, o.av1, o.bv);
+    }
+    mfma16_fence(acc0, acc1);
+    dq_add(acc0, acc1, ph, ppb);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int key = key0 + t * 32 + lr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { mfma32_fence_agpr(dk[t][i]); mfma32_fence_agpr(dv[t][i]); }     // written back before the accumulators are read
+    if (key < a.N && a.qsplit > 1) {
+      const long prow = ((long)part * a.B + b) * a.N + key;
+      store_grad_row(a.wsk + prow * D, dk[t], 1.f, nullptr, nullptr, lh);
+      store_grad_row(a.wsv + prow * D, dv[t], 1.f, nullptr, nullptr, lh);
+    } else if (key < a.N) {
+      store_grad(a.dk, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dk[t], a.scale, a.rcos, a.rsin, key, lh);
+      store_grad(a.dv, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dv[t], 1.f, nullptr, nullptr, key, lh);
+    }
+  }
+}
+
 // finishing pass of the fused backward's dQ: fp32 sums [M][H*64] -> scale, RoPE transpose (as store_grad_row), cast, into dq [M][lddq]
 template <typename TO>
 __global__ __launch_bounds__(256) void dq_finish_kernel(const float* __restrict__ dq32, TO* dq, long lddq, long M, int N, int H, float scale,
@@ -1398,9 +1682,29 @@ static long fused_dq_bytes(int B, int H, int N, int out_dtype, int dq_mode) {
   const long npad = ((long)N + 31) / 32 * 32, nkb = ((long)N + 255) / 256;
   return ((nkb * B * npad * H * D * (out_dtype == OSUF_DT_BF16 ? 2 : 4)) + 15) / 16 * 16;
 }
+// Which sweep an atomic-dQ call runs, and in how many query parts.  512 keys per workgroup (mqa_bwd_fused512_kernel) halves the dQ
+// atomic bytes but gives half as many workgroups: it is taken where whole 32-query blocks and enough work per part remain.
+static bool fused_use512(int B, int N, int dq_mode) {
+  if (dq_mode == OSUF_DQ_ATOMIC_512 || dq_mode == OSUF_DQ_TIMING_512) return true;
+  if (dq_mode != OSUF_DQ_ATOMIC) return false;
+  return (N % 32) == 0 && N >= 2048;
+}
+static int fused512_qsplit(int B, int N, int forced) {
+  if (forced > 0) return forced;
+  const int blocks = ((N + 511) / 512) * ((B + 7) / 8 * 8);
+  int sp = 1;
+  while (sp < 8 && blocks * sp < 256 && (N / 32) / (sp * 2) >= 8) sp *= 2;
+  return sp;
+}
+static bool fused_mode_ok(int dq_mode) { return dq_mode >= OSUF_DQ_ATOMIC && dq_mode <= OSUF_DQ_TIMING_512; }
+static long fused_dkv_ws_bytes(int B, int N, int qsplit, int dq_mode) {
+  if (!fused_use512(B, N, dq_mode)) return osuf_mqa_bwd_dkv_workspace_bytes(B, N, qsplit);
+  const int sp = fused512_qsplit(B, N, qsplit);
+  return sp > 1 ? 2L * sp * B * N * D * (long)sizeof(float) : 0;
+}
 extern "C" long osuf_mqa_bwd_fused_workspace_bytes(int B, int H, int N, int out_dtype, int qsplit, int dq_mode) {
-  if (B <= 0 || H <= 0 || N <= 0 || qsplit < 0 || qsplit > 16 || (dq_mode != OSUF_DQ_ATOMIC && dq_mode != OSUF_DQ_SLABS)) return 0;
-  return fused_dq_bytes(B, H, N, out_dtype, dq_mode) + osuf_mqa_bwd_dkv_workspace_bytes(B, N, qsplit);
+  if (B <= 0 || H <= 0 || N <= 0 || qsplit < 0 || qsplit > 16 || !fused_mode_ok(dq_mode)) return 0;
+  return fused_dq_bytes(B, H, N, out_dtype, dq_mode) + fused_dkv_ws_bytes(B, N, qsplit, dq_mode);
 }
 
 extern "C" int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
@@ -1412,34 +1716,46 @@ extern "C" int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long l
   if (rc) return rc;
   if (lddq % 8 || lddk % 8 || !al16(dq) || !al16(dk) || !al16(dv) || (out_dtype != OSUF_DT_F32 && out_dtype != OSUF_DT_BF16) ||
       ((rope_cos == nullptr) != (rope_sin == nullptr)) || qsplit < 0 || qsplit > 16 || !workspace || !al16(workspace) ||
-      (dq_mode != OSUF_DQ_ATOMIC && dq_mode != OSUF_DQ_SLABS) || workspace_bytes < osuf_mqa_bwd_fused_workspace_bytes(B, H, N, out_dtype, qsplit, dq_mode))
+      !fused_mode_ok(dq_mode) || workspace_bytes < osuf_mqa_bwd_fused_workspace_bytes(B, H, N, out_dtype, qsplit, dq_mode))
     return OSUF_EINVAL;
+  const bool use512 = fused_use512(B, N, dq_mode);
+  if (use512 && (N % 32) != 0) return OSUF_EUNSUPPORTED;           // the 512-key sweep is written for whole 32-query blocks
   a.dk = dk; a.dv = dv; a.lddk = lddk; a.g_bf16 = out_dtype == OSUF_DT_BF16; a.rcos = rope_cos; a.rsin = rope_sin;
   const long M = (long)B * N;
   const long dq_bytes = fused_dq_bytes(B, H, N, out_dtype, dq_mode);
   float* dq32 = workspace;
   float* wsp = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + dq_bytes);
-  a.qsplit = dkv_qsplit(B, N, qsplit);
+  a.qsplit = use512 ? fused512_qsplit(B, N, qsplit) : dkv_qsplit(B, N, qsplit);
   if (a.qsplit > 1) { a.wsk = wsp; a.wsv = wsp + (long)a.qsplit * B * N * D; }
-  const int lds = 2 * (4096 + 4096 + 256) + 32768 + 2 * 16384;
-  const bool ragged = (N % 32) != 0;
-  const int mode = dq_mode == OSUF_DQ_ATOMIC ? 0 : (a.g_bf16 ? 1 : 2);
-  void (*kern)(AttnArgs, float*) =
-      mode == 0 ? (ragged ? mqa_bwd_fused_kernel<0, true> : mqa_bwd_fused_kernel<0, false>)
-    : mode == 1 ? (ragged ? mqa_bwd_fused_kernel<1, true> : mqa_bwd_fused_kernel<1, false>)
-                : (ragged ? mqa_bwd_fused_kernel<2, true> : mqa_bwd_fused_kernel<2, false>);
-  static bool attr_set[6] = {false, false, false, false, false, false};
-  if (!attr_set[2 * mode + ragged]) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set[2 * mode + ragged] = true;
-  }
   const int b8 = (B + 7) / 8 * 8;
-  const dim3 grid(((N + 255) / 256) * b8 * a.qsplit);
-  if (dq_mode == OSUF_DQ_ATOMIC) {
+  if (dq_mode != OSUF_DQ_SLABS) {
     hipError_t e = hipMemsetAsync(dq32, 0, (size_t)dq_bytes, stream);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a, dq32);
+  if (use512) {
+    const int lds = 2 * (4096 + 4096 + 256) + 65536 + 2 * 32768;
+    void (*kern)(AttnArgs, float*) = dq_mode == OSUF_DQ_TIMING_512 ? mqa_bwd_fused512_kernel<false> : mqa_bwd_fused512_kernel<true>;
+    static bool attr512[2] = {false, false};
+    if (!attr512[dq_mode == OSUF_DQ_TIMING_512]) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr512[dq_mode == OSUF_DQ_TIMING_512] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(((N + 511) / 512) * b8 * a.qsplit), dim3(256), lds, stream, a, dq32);
+  } else {
+    const int lds = 2 * (4096 + 4096 + 256) + 32768 + 2 * 16384;
+    const bool ragged = (N % 32) != 0;
+    const int mode = dq_mode != OSUF_DQ_SLABS ? 0 : (a.g_bf16 ? 1 : 2);
+    void (*kern)(AttnArgs, float*) =
+        mode == 0 ? (ragged ? mqa_bwd_fused_kernel<0, true> : mqa_bwd_fused_kernel<0, false>)
+      : mode == 1 ? (ragged ? mqa_bwd_fused_kernel<1, true> : mqa_bwd_fused_kernel<1, false>)
+                  : (ragged ? mqa_bwd_fused_kernel<2, true> : mqa_bwd_fused_kernel<2, false>);
+    static bool attr_set[6] = {false, false, false, false, false, false};
+    if (!attr_set[2 * mode + ragged]) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set[2 * mode + ragged] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(((N + 255) / 256) * b8 * a.qsplit), dim3(512), lds, stream, a, dq32);
+  }
   if (a.qsplit > 1) {
     const unsigned fb = (unsigned)((M * 32 + 255) / 256);
     if (a.g_bf16) hipLaunchKernelGGL(dkv_finish_kernel<bf16_t>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (bf16_t*)dk, (bf16_t*)dv, lddk, M, N, scale, rope_cos, rope_sin);

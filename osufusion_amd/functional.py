@@ -515,7 +515,9 @@ def film_group(x: torch.Tensor, linears, mode_dtype: torch.dtype, in_act: int):
     complete (grad_used) when its block's backward has produced dy_i."""
     ws = tuple(l.weight for l in linears)
     bs = tuple(l.bias for l in linears)
-    direct = _DIRECT and _GRAD_COMPLETE_CB is not None and torch.is_grad_enabled() and \
+    # (x must carry a graph: the taps hang off the group node's outputs, and with detached weights an input without one would leave
+    #  the outputs -- and so the FiLM weights -- without any gradient path)
+    direct = _DIRECT and _GRAD_COMPLETE_CB is not None and torch.is_grad_enabled() and x.requires_grad and \
         all(not w.requires_grad or grad_target(w) is not None for w in ws) and \
         all(b is None or not b.requires_grad or grad_target(b) is not None for b in bs)
     if direct:

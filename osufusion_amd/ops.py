@@ -407,6 +407,8 @@ def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.
 
 
 ATTN_AUTO, ATTN_PLAIN, ATTN_PIPE, ATTN_FUSED, ATTN_FUSED_SLABS = 0, 1, 2, 3, 4
+ATTN_FUSED256, ATTN_FUSED512, ATTN_FUSED512_TIMING = 5, 6, 7     # force the 256- / 512-key sweep of ATTN_FUSED; 512 without atomics (timing only)
+_FUSED_DQ_MODE = {ATTN_FUSED: 0, ATTN_FUSED_SLABS: 1, ATTN_FUSED256: 2, ATTN_FUSED512: 3, ATTN_FUSED512_TIMING: 4}      # OSUF_DQ_*
 # What AttentionFn.backward asks for: ATTN_FUSED = one key-stationary sweep, dQ by fp32 atomics (fastest at every UNet shape, measured
 # round 2); ATTN_FUSED_SLABS = the same sweep with a fixed-order dQ sum (bit-reproducible); ATTN_AUTO = the dQ + dK/dV kernel pair.
 ATTN_BWD_DEFAULT = ATTN_FUSED
@@ -434,8 +436,8 @@ def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Ten
         q_, k_, v_ = qkv.data_ptr() + 2 * g * r * D, qkv.data_ptr() + 2 * (H + g) * D, qkv.data_ptr() + 2 * (H + G + g) * D
         dq_, dk_, dv_ = dqkv.data_ptr() + es * g * r * D, dqkv.data_ptr() + es * (H + g) * D, dqkv.data_ptr() + es * (H + G + g) * D
         do_, lse_, delta_ = do.data_ptr() + 2 * g * r * D, lse.data_ptr() + 4 * g * B * r * N, delta.data_ptr() + 4 * g * B * r * N
-        if variant in (ATTN_FUSED, ATTN_FUSED_SLABS):
-            mode = 1 if variant == ATTN_FUSED_SLABS else 0                        # OSUF_DQ_SLABS / OSUF_DQ_ATOMIC
+        if variant in _FUSED_DQ_MODE:
+            mode = _FUSED_DQ_MODE[variant]
             need = _lib.load().osuf_mqa_bwd_fused_workspace_bytes(B, r, N, _DT[out_dtype], qsplit, mode)
             ws = _workspace(need, qkv.device)
             call("osuf_mqa_bwd_fused", q_, ld, k_, ld, v_, ld, do_, ldo_, lse_, delta_, dq_, W, dk_, dv_, W, B, r, N, D, scale, _DT[out_dtype],

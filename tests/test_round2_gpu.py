@@ -45,7 +45,7 @@ def test_fused_attention_backward_beyond_eight_samples():
     o, lse = ops.mqa_fwd(qkv, Bn, N, H, D, torch.bfloat16, D ** -0.5)
     assert rell2(o.float(), o_ref) < 5e-3
     for name, variant, qsplit in (("fused", ops.ATTN_FUSED, 0), ("fused-split2", ops.ATTN_FUSED, 2), ("fused-slabs", ops.ATTN_FUSED_SLABS, 0),
-                                  ("auto", ops.ATTN_AUTO, 0)):
+                                  ("auto", ops.ATTN_AUTO, 0), ("fused512", ops.ATTN_FUSED512, 1), ("fused512-split4", ops.ATTN_FUSED512, 4)):
         dqkv = ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5, variant=variant, qsplit=qsplit)
         for bi in range(Bn):                                               # per sample: a mis-placed sample is an O(1) error on it alone
             e = rell2(dqkv[bi], g_ref[bi])
@@ -64,7 +64,9 @@ def test_every_attention_backward_kernel_vs_fp32_autograd(N):
     assert rell2(o.float(), o_ref) < 5e-3                              # bf16 P and bf16 output rounding
     cases = [("auto", ops.ATTN_AUTO, 0), ("plain", ops.ATTN_PLAIN, 0), ("pipe-unsplit", ops.ATTN_PIPE, 1), ("pipe-split2", ops.ATTN_PIPE, 2),
              ("pipe-split4", ops.ATTN_PIPE, 4), ("fused", ops.ATTN_FUSED, 0), ("fused-split2", ops.ATTN_FUSED, 2),
-             ("fused-slabs", ops.ATTN_FUSED_SLABS, 0)]
+             ("fused-slabs", ops.ATTN_FUSED_SLABS, 0), ("fused256", ops.ATTN_FUSED256, 0)]
+    if N % 32 == 0:                                                    # round 3: the 4-wave, 512-keys-per-workgroup sweep (whole query blocks)
+        cases += [("fused512", ops.ATTN_FUSED512, 1), ("fused512-split2", ops.ATTN_FUSED512, 2), ("fused512-auto", ops.ATTN_FUSED512, 0)]
     outs = {}
     for name, variant, qsplit in cases:
         dqkv = ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5, variant=variant, qsplit=qsplit)

@@ -81,7 +81,7 @@ def test_resblock_applied_twice_reports_film_gradient_once(golden_dir):
     for p in blk.parameters():
         p.data.normal_(0, 0.2)
     x = torch.randn(2, 32, 64, device=DEV)
-    te, ce = torch.randn(2, 64, device=DEV), torch.randn(2, 64, device=DEV)
+    te, ce = torch.randn(2, 64, device=DEV, requires_grad=True), torch.randn(2, 64, device=DEV)   # (in the UNet: time_mlp's output)
 
     def run(group):
         for p in blk.parameters():
