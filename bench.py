@@ -166,8 +166,9 @@ def main() -> None:
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-sampler", action="store_true", help="skip the secondary metric (one 50-step DDIM sample at BASELINE config 4's size)")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the extra fp32-compute-mode step (the mode in which the 1e-3 parity bound holds)")
-    ap.add_argument("--attn-bwd", choices=["auto", "pair", "fused", "slabs"], default="auto",
-                    help="attention backward: auto = the library default (fused sweep, atomic dQ); pair = dQ + dK/dV kernels; slabs = fused, fixed-order dQ")
+    ap.add_argument("--attn-bwd", choices=["auto", "pair", "fused", "fused256", "fused512", "slabs"], default="auto",
+                    help="attention backward: auto = the library default (fused sweep, atomic dQ, 256 or 512 keys per workgroup by shape); "
+                         "fused256 / fused512 = force that sweep (A/B); pair = dQ + dK/dV kernels; slabs = fused, fixed-order dQ")
     ap.add_argument("--no-fuse-rowdot", action="store_true", help="A/B: sum(dO*O) by the stand-alone pass instead of the to_out dgrad epilogue")
     args = ap.parse_args()
 
@@ -200,7 +201,8 @@ def main() -> None:
     if args.no_fuse_rowdot:
         ops.FUSE_ROWDOT = False
     if args.attn_bwd != "auto":
-        ops.ATTN_BWD_DEFAULT = {"fused": ops.ATTN_FUSED, "slabs": ops.ATTN_FUSED_SLABS, "pair": ops.ATTN_AUTO}[args.attn_bwd]
+        ops.ATTN_BWD_DEFAULT = {"fused": ops.ATTN_FUSED, "slabs": ops.ATTN_FUSED_SLABS, "pair": ops.ATTN_AUTO, "fused256": ops.ATTN_FUSED256,
+                                "fused512": ops.ATTN_FUSED512}[args.attn_bwd]
     trainer = Trainer(model, lr=1e-4, weight_decay=1e-2, clip_grad_norm=1.0, compute_dtype=torch.bfloat16)
     x, a, c, noise, t = synth_batch(rank, device, args.batch, args.length)
 

@@ -1102,13 +1102,24 @@ __global__ __launch_bounds__(512) void mqa_bwd_fused_kernel(AttnArgs a, float* d
 __device__ __forceinline__ int ds_img_off512(int key, int qchunk) {
   return key * 64 + ((qchunk ^ ((key ^ ((key >> 3) & 3)) & 7)) << 3);
 }
-__device__ __forceinline__ void mfma32_agpr(f32x16& acc, const bf16x8 a, const bf16x8 b) {
-  asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+__device__ __forceinline__ void mfma32_agpr(f32x16& acc, const bf16x8 a, const bf16x8 b) {      // (P / dS fragments: converted >= 2 instructions earlier, see the slots)
+  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
+// (no leading s_nop on these two: their A / B operands come out of LDS reads or loop-invariant registers and their accumulators out of LDS
+//  reads or the previous MFMA of the chain -- never out of a VALU instruction issued just before; tools/check_mfma_hazards.py checks the
+//  emitted code for a VALU write of an MFMA source within the two preceding instructions)
 __device__ __forceinline__ void mfma32_vgpr(f32x16& acc, const bf16x8 a, const bf16x8 b) {
-  asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma16_vgpr(f32x4& acc, const bf16x8 a, const bf16x8 b) {
+  asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// an MFMA right behind the v_cvt_pk that produced its B operand (hipcc is free to sink the fillers written between them)
+__device__ __forceinline__ void mfma32_agpr_nop(f32x16& acc, const bf16x8 a, const bf16x8 b) {
+  asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// first MFMA of a dQ chain: its accumulator was zeroed by VALU moves that hipcc may place right in front of it
+__device__ __forceinline__ void mfma16_vgpr_first(f32x4& acc, const bf16x8 a, const bf16x8 b) {
   asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 // results of asm MFMAs become readable by the VALU / stores only after the matrix pipe has written them back
@@ -1172,21 +1183,29 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512_kernel(AttnArgs a, fl
   const int lrow = tid >> 3, lchunk = tid & 7;
   const unsigned qoff = (unsigned)(lrow * (int)a.ldq + lchunk * 8), dooff = (unsigned)(lrow * (int)a.lddo + lchunk * 8);
   const int lds_dst = tile_off(lrow, lchunk * 16);
-  const float* ssrc = (tid & 32) ? a.delta : a.lse2;
   const float smul = (tid & 32) ? -1.f : -1.f / c;
   const int last_pb = qb_end - 1;
   u32x4 rq, rd; float rs = 0.f;
-  int ih = 0, ipb = qb_begin;                                     // (head, query block) of the next stage to load
+  // (head, query block) of the next stage to load, as running wave-uniform pointers: +64 columns per head, and at the last head on to the
+  // next block's rows (past the end: the last pair again -- loaded, never consumed)
+  int ih = 0, ipb = qb_begin;
+  const bf16_t* qp_ = a.q + ((long)b * a.N + qb_begin * 32) * a.ldq;
+  const bf16_t* dp_ = a.dout + ((long)b * a.N + qb_begin * 32) * a.lddo;
+  const float* lp_ = a.lse2 + (long)b * a.H * a.N + qb_begin * 32;
+  const float* tp_ = a.delta + (long)b * a.H * a.N + qb_begin * 32;
+  const long q_wrap = 32 * a.ldq - (long)(a.H - 1) * D, d_wrap = 32 * a.lddo - (long)(a.H - 1) * D, s_wrap = 32 - (long)(a.H - 1) * a.N;
   auto load_stage = [&]() {
-    const int pbc = min(ipb, last_pb);                             // past the end: reload the last block (never consumed)
-    const long row0 = (long)b * a.N + pbc * 32;
-    const bf16_t* qb_ = a.q + row0 * a.ldq + ih * D;               // scalar bases
-    const bf16_t* db_ = a.dout + row0 * a.lddo + ih * D;
-    const float* sb = ssrc + ((long)b * a.H + ih) * a.N + pbc * 32;
-    rq = *reinterpret_cast<const u32x4*>(qb_ + qoff);
-    rd = *reinterpret_cast<const u32x4*>(db_ + dooff);
-    rs = sb[(unsigned)(tid & 31)] * smul;
-    if (++ih == a.H) { ih = 0; ++ipb; }
+    rq = *reinterpret_cast<const u32x4*>(qp_ + qoff);
+    rd = *reinterpret_cast<const u32x4*>(dp_ + dooff);
+    rs = ((tid & 32) ? tp_ : lp_)[(unsigned)(tid & 31)] * smul;
+    const bool wrap = ih + 1 == a.H;
+    const bool stay = wrap && ipb == last_pb;                      // scalar selects
+    ih = wrap ? 0 : ih + 1;
+    ipb += (wrap && !stay) ? 1 : 0;
+    const long dq_ = stay ? -(long)(a.H - 1) * D : (wrap ? q_wrap : (long)D);
+    const long dd_ = stay ? -(long)(a.H - 1) * D : (wrap ? d_wrap : (long)D);
+    const long ds_ = stay ? -(long)(a.H - 1) * a.N : (wrap ? s_wrap : (long)a.N);
+    qp_ += dq_; dp_ += dd_; lp_ += ds_; tp_ += ds_;
   };
   auto store_stage = [&](int slot) {
     char* base = smem + slot * kStage;
@@ -1205,6 +1224,17 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512_kernel(AttnArgs a, fl
   // a wave-uniform 64-bit base + a 32-bit per-lane BYTE offset (the saddr form): eight zero-extended 64-bit lane offsets would not fit the file
   const unsigned aoffb = (unsigned)((4 * g4) * (a.H * D) + wave * 16 + ip) * 4u;
   const unsigned rowb = (unsigned)(a.H * D) * 4u;
+  auto dq_add2 = [&](const f32x4& q0, const f32x4& q1, int r, int ph_, int ppb_) {      // row r of both query halves
+    if constexpr (ATOMICS) {
+      char* sb = reinterpret_cast<char*>(dq32 + ((long)b * a.N + ppb_ * 32) * (a.H * D) + ph_ * D);      // scalar
+      unsigned ob = aoffb;
+      asm volatile("" : "+v"(ob));
+      atomic_add_f32(reinterpret_cast<float*>(sb + (ob + (unsigned)r * rowb)), q0[r]);
+      atomic_add_f32(reinterpret_cast<float*>(sb + (ob + (unsigned)(16 + r) * rowb)), q1[r]);
+    } else {
+      asm volatile("" :: "v"(q0[r]), "v"(q1[r]));
+    }
+  };
   auto dq_add = [&](const f32x4& q0, const f32x4& q1, int ph_, int ppb_) {
     if constexpr (ATOMICS) {
       char* sb = reinterpret_cast<char*>(dq32 + ((long)b * a.N + ppb_ * 32) * (a.H * D) + ph_ * D);      // scalar
@@ -1257,18 +1287,25 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512_kernel(AttnArgs a, fl
     };
     bf16x8 qa[4], da[4], kf[4];
     f32x16 s, dp;
-    auto read_tile_consts = [&]() {                                // the initial accumulators of a key tile's S / dP chains: -lse/c, -delta
+    auto read_consts_s = [&]() {                                   // the initial accumulators of a key tile's S / dP chains: -lse/c, -delta
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(ls + 8 * g + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[4 * g + e] = l4[e];
+      }
+    };
+    auto read_consts_dp = [&]() {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(ls + 32 + 8 * g + 4 * lh);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { s[4 * g + e] = l4[e]; dp[4 * g + e] = d4[e]; }
+        for (int e = 0; e < 4; ++e) dp[4 * g + e] = d4[e];
       }
     };
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { qa[ks] = lds_row_frag(qs, lo, ks, 0); da[ks] = lds_row_frag(dos, lo, ks, 0); }
-    read_tile_consts();
+    read_consts_s(); read_consts_dp();
     kf[0] = lds_row_frag(kimg + wave * 4 * 4096, lo, 0, 0); kf[1] = lds_row_frag(kimg + wave * 4 * 4096, lo, 1, 0);
     DqOps o0 = dq_read(ep, 0);
 #pragma unroll
@@ -1301,32 +1338,40 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512_kernel(AttnArgs a, fl
       // slot = one matrix instruction (or a dQ pair), then the fillers that issue while it executes; OSUF_FENCE pins the order.
       // Fragment reads sit as late as their consumers allow (two slots ahead or more): the register file is full
       const char* krow = kimg + (wave * 4 + t) * 4096;
+      // dQ k-steps: tiles 0-2 run theirs in slots 2, 9, 16, 17; the last tile runs them early (slots 2, 6, 9, 10) so that the eight float
+      // atomics of the finished tiles can leave one or two per slot behind its dV / dK MFMAs instead of as one burst before the barrier
+      constexpr bool kLast = false;
+      const bool last = t == 3;
       OSUF_FENCE;
       mfma32_vgpr(s, qa[0], kf[0]);                 OSUF_FENCE;  o1 = dq_read(ep, 4 * t + 1); kf[2] = lds_row_frag(krow, lo, 2, 0); kf[3] = lds_row_frag(krow, lo, 3, 0);  OSUF_FENCE;
-      mfma32_vgpr(s, qa[1], kf[1]);                 OSUF_FENCE;  dq_mma(o0);                                                    OSUF_FENCE;   // k-step 4t
+      mfma32_vgpr(s, qa[1], kf[1]);                 OSUF_FENCE;
+      if (t == 0) { mfma16_vgpr_first(acc0, o0.av0, o0.bv); mfma16_vgpr_first(acc1, o0.av1, o0.bv); } else dq_mma(o0);          OSUF_FENCE;   // k-step 4t
       mfma32_vgpr(s, qa[2], kf[2]);                 OSUF_FENCE;  trd[0][0] = lds_tr_frag(dos, lo, 0, 0); trd[0][1] = lds_tr_frag(dos, lo, 0, 1);   OSUF_FENCE;
       mfma32_vgpr(s, qa[3], kf[3]);                 OSUF_FENCE;  o0 = dq_read(ep, 4 * t + 2);                                   OSUF_FENCE;
       mfma32_vgpr(dp, da[0], vf[t][0]);             OSUF_FENCE;  trd[1][0] = lds_tr_frag(dos, lo, 16, 0); trd[1][1] = lds_tr_frag(dos, lo, 16, 1); OSUF_FENCE;
-      mfma32_vgpr(dp, da[1], vf[t][1]);             OSUF_FENCE;
+      mfma32_vgpr(dp, da[1], vf[t][1]);             OSUF_FENCE;  if (last) { dq_mma(o1); o1 = dq_read(ep, 15); }                OSUF_FENCE;   // (last tile: k-step 13)
       mfma32_vgpr(dp, da[2], vf[t][2]);             OSUF_FENCE;  mfma32_fence_short(s); exp4(0);                                OSUF_FENCE;
       mfma32_vgpr(dp, da[3], vf[t][3]);             OSUF_FENCE;  exp4(4);                                                       OSUF_FENCE;
-      dq_mma(o1);                                   OSUF_FENCE;  exp4(8); pf[0] = acc_to_frag(s, 0);                            OSUF_FENCE;   // k-step 4t+1
-      mfma32_agpr(dv[t][0], trd[0][0], pf[0]);      OSUF_FENCE;  exp4(12);                                                      OSUF_FENCE;
-      mfma32_agpr(dv[t][1], trd[0][1], pf[0]);      OSUF_FENCE;  pf[1] = acc_to_frag(s, 1); mfma32_fence_short(dp); ds4(0);
+      if (last) dq_mma(o0); else dq_mma(o1);        OSUF_FENCE;  pf[0] = acc_to_frag(s, 0); OSUF_FENCE; exp4(8);                OSUF_FENCE;   // k-step 4t+1 (last tile: 14)
+      mfma32_agpr_nop(dv[t][0], trd[0][0], pf[0]);  OSUF_FENCE;  exp4(12); if (last) dq_mma(o1);                                OSUF_FENCE;   // (last tile: k-step 15)
+      mfma32_agpr(dv[t][1], trd[0][1], pf[0]);      OSUF_FENCE;  pf[1] = acc_to_frag(s, 1); OSUF_FENCE; mfma32_fence_short(dp); ds4(0);
                                                                  trq[0][0] = lds_tr_frag(qs, lo, 0, 0); trq[0][1] = lds_tr_frag(qs, lo, 0, 1);     OSUF_FENCE;
-      mfma32_agpr(dv[t][0], trd[1][0], pf[1]);      OSUF_FENCE;  ds4(4); ds4(8);                                                OSUF_FENCE;
-      mfma32_agpr(dv[t][1], trd[1][1], pf[1]);      OSUF_FENCE;  ds4(12); df[0] = acc_to_frag(dp, 0);
+      mfma32_agpr(dv[t][0], trd[1][0], pf[1]);      OSUF_FENCE;  ds4(4); ds4(8); if (last) mfma16_fence(acc0, acc1);            OSUF_FENCE;
+      mfma32_agpr(dv[t][1], trd[1][1], pf[1]);      OSUF_FENCE;  ds4(12); df[0] = acc_to_frag(dp, 0); OSUF_FENCE;
                                                                  trq[1][0] = lds_tr_frag(qs, lo, 16, 0); trq[1][1] = lds_tr_frag(qs, lo, 16, 1);   OSUF_FENCE;
-      mfma32_agpr(dk[t][0], trq[0][0], df[0]);      OSUF_FENCE;  df[1] = acc_to_frag(dp, 1); ds_write2(0);                      OSUF_FENCE;
-      mfma32_agpr(dk[t][1], trq[0][1], df[0]);      OSUF_FENCE;  ds_write2(2); o1 = dq_read(ep, 4 * t + 3);                     OSUF_FENCE;
-      mfma32_agpr(dk[t][0], trq[1][0], df[1]);      OSUF_FENCE;  dq_mma(o0); if (t < 3) read_tile_consts();                     OSUF_FENCE;   // k-step 4t+2
-      mfma32_agpr(dk[t][1], trq[1][1], df[1]);      OSUF_FENCE;  dq_mma(o1);                                                                  // k-step 4t+3
-      if (t < 3) { o0 = dq_read(ep, 4 * t + 4); kf[0] = lds_row_frag(krow + 4096, lo, 0, 0); kf[1] = lds_row_frag(krow + 4096, lo, 1, 0); }
+      // (the next tile's first operands -- initial accumulators, K fragments 0 and 1 -- are read three slots ahead of its first MFMA)
+      mfma32_agpr(dk[t][0], trq[0][0], df[0]);      OSUF_FENCE;  df[1] = acc_to_frag(dp, 1); OSUF_FENCE; ds_write2(0);
+                                                                 if (last) dq_add2(acc0, acc1, 0, ph, ppb); else read_consts_s();                   OSUF_FENCE;
+      mfma32_agpr(dk[t][1], trq[0][1], df[0]);      OSUF_FENCE;  ds_write2(2);
+                                                                 if (last) dq_add2(acc0, acc1, 1, ph, ppb); else { o1 = dq_read(ep, 4 * t + 3); read_consts_dp(); }   OSUF_FENCE;
+      mfma32_agpr(dk[t][0], trq[1][0], df[1]);      OSUF_FENCE;
+      if (last) dq_add2(acc0, acc1, 2, ph, ppb);
+      else { dq_mma(o0); kf[0] = lds_row_frag(krow + 4096, lo, 0, 0); kf[1] = lds_row_frag(krow + 4096, lo, 1, 0); }                                OSUF_FENCE;   // k-step 4t+2
+      mfma32_agpr(dk[t][1], trq[1][1], df[1]);      OSUF_FENCE;
+      if (last) dq_add2(acc0, acc1, 3, ph, ppb); else { dq_mma(o1); o0 = dq_read(ep, 4 * t + 4); }                                                                // k-step 4t+3
+      (void)kLast;
     }
     OSUF_FENCE;
-    // the previous pair's dQ tiles: accumulator column n = lane & 15 -> d, row m = 4 * (lane >> 4) + r -> query (of its half)
-    mfma16_fence(acc0, acc1);
-    dq_add(acc0, acc1, ph, ppb);
     store_stage((it + 1) & 1);                                     // (after the last pair: a stage nobody reads)
     __syncthreads();
     ph = ch; ppb = cpb;
@@ -1339,8 +1384,8 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512_kernel(AttnArgs a, fl
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       const DqOps o = dq_read(ep, ks);
-      mfma16_vgpr(acc0, o.av0, o.bv);
-      mfma16_vgpr(acc1, o.av1, o.bv);
+      if (ks == 0) { mfma16_vgpr_first(acc0, o.av0, o.bv); mfma16_vgpr_first(acc1, o.av1, o.bv); }
+      else { mfma16_vgpr(acc0, o.av0, o.bv); mfma16_vgpr(acc1, o.av1, o.bv); }
     }
     mfma16_fence(acc0, acc1);
     dq_add(acc0, acc1, ph, ppb);
@@ -1687,7 +1732,7 @@ static long fused_dq_bytes(int B, int H, int N, int out_dtype, int dq_mode) {
 static bool fused_use512(int B, int N, int dq_mode) {
   if (dq_mode == OSUF_DQ_ATOMIC_512 || dq_mode == OSUF_DQ_TIMING_512) return true;
   if (dq_mode != OSUF_DQ_ATOMIC) return false;
-  return (N % 32) == 0 && N >= 2048;
+  return (N % 32) == 0 && N >= 1024;
 }
 static int fused512_qsplit(int B, int N, int forced) {
   if (forced > 0) return forced;

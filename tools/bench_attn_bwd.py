@@ -13,7 +13,7 @@ def timeit(fn, iters=8):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
-for N in ([int(a) for a in sys.argv[1:]] or [4096, 2048, 1024]):
+for N in ([int(a) for a in sys.argv[1:]] or [4096, 2048, 1024, 512]):
     qkv = torch.randn(B, N, (H + 2) * D, device="cuda").to(torch.bfloat16)
     o, lse = ops.mqa_fwd(qkv, B, N, H, D, torch.bfloat16, D ** -0.5)
     do = torch.randn(B, N, H * D, device="cuda").to(torch.bfloat16)
