@@ -1599,6 +1599,8 @@ __global__ __launch_bounds__(256) void rope_bwd_kernel(const float* in, long ld_
 // ------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------
+#include "attn_generic.hpp"
+
 static inline int ew_grid(long total_threads) {
   long blocks = (total_threads + 255) / 256;
   if (blocks > 4096) blocks = 4096;
@@ -1606,21 +1608,29 @@ static inline int ew_grid(long total_threads) {
   return (int)blocks;
 }
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// head dims served by the generic kernels of attn_generic.hpp (64 has the tuned kernels of this file): padded tile width, 0 = unsupported
+static int gen_dp(int head_dim) { return head_dim == 16 || head_dim == 32 ? 32 : head_dim == 128 ? 128 : 0; }
 extern "C" int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
                             float* lse2, int B, int H, int N, int head_dim, float scale, hipStream_t stream) {
-  if (head_dim != D) return OSUF_EUNSUPPORTED;
+  if (head_dim != D && !gen_dp(head_dim)) return OSUF_EUNSUPPORTED;
   if (B <= 0 || H <= 0 || N <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || !al16(q) || !al16(k) || !al16(v) || !al16(o)) return OSUF_EINVAL;
   AttnArgs a = {};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
   a.o = o; a.ldo = ldo; a.o_is_f32 = o_dtype == OSUF_DT_F32; a.lse2 = lse2; a.B = B; a.H = H; a.N = N; a.scale = scale;
   const int nvb = ((N + 31) / 32) * H;
+  if (head_dim != D) {
+    const dim3 grid((nvb + 3) / 4, B);
+    if (gen_dp(head_dim) == 32) hipLaunchKernelGGL(mqa_gen_fwd_kernel<32>, grid, dim3(256), 2 * 64 * 64, stream, a, head_dim);
+    else hipLaunchKernelGGL(mqa_gen_fwd_kernel<128>, grid, dim3(256), 2 * 64 * 256, stream, a, head_dim);
+    return osuf_launch_status();
+  }
   hipLaunchKernelGGL(mqa_fwd_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768 + 8 * 4096, stream, a);
   return osuf_launch_status();
 }
 
 static int fill_bwd_args(AttnArgs& a, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
                          const float* lse2, const float* delta, int B, int H, int N, int head_dim, float scale) {
-  if (head_dim != D) return OSUF_EUNSUPPORTED;
+  if (head_dim != D && !gen_dp(head_dim)) return OSUF_EUNSUPPORTED;
   if (B <= 0 || H <= 0 || N <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || lddo % 8) return OSUF_EINVAL;
   if (!al16(q) || !al16(k) || !al16(v) || !al16(dout)) return OSUF_EINVAL;
   a = AttnArgs{};
@@ -1633,8 +1643,14 @@ static int fill_bwd_args(AttnArgs& a, const void* q, long ldq, const void* k, lo
 // delta[b][h][n] = sum_d dO * O   (o: bf16 or f32 storage of the forward output)
 extern "C" int osuf_attn_delta(const void* dout, long lddo, const void* o, long ldo, int o_dtype, float* delta, int B, int H, int N,
                                int head_dim, hipStream_t stream) {
-  if (head_dim != D) return OSUF_EUNSUPPORTED;
+  if (head_dim != D && !gen_dp(head_dim)) return OSUF_EUNSUPPORTED;
   if (B <= 0 || H <= 0 || N <= 0 || ldo % 8 || lddo % 8 || !al16(o) || !al16(dout)) return OSUF_EINVAL;
+  if (head_dim != D) {
+    const int gb = ew_grid((long)B * N * H);
+    if (o_dtype == OSUF_DT_F32) hipLaunchKernelGGL(attn_delta_gen_kernel<float>, dim3(gb), dim3(256), 0, stream, (const bf16_t*)dout, lddo, (const float*)o, ldo, delta, B, H, N, head_dim);
+    else hipLaunchKernelGGL(attn_delta_gen_kernel<bf16_t>, dim3(gb), dim3(256), 0, stream, (const bf16_t*)dout, lddo, (const bf16_t*)o, ldo, delta, B, H, N, head_dim);
+    return osuf_launch_status();
+  }
   const long tot = (long)B * N * H * 8;
   if (o_dtype == OSUF_DT_F32) {
     hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(ew_grid(tot)), dim3(256), 0, stream, (const bf16_t*)dout, lddo, (const float*)o, ldo, delta, B, H, N);
@@ -1657,6 +1673,13 @@ extern "C" int osuf_mqa_bwd_dq(const void* q, long ldq, const void* k, long ldk,
     return OSUF_EINVAL;
   a.dq = dq; a.lddq = lddq; a.g_bf16 = out_dtype == OSUF_DT_BF16; a.rcos = rope_cos; a.rsin = rope_sin;
   const int nvb = ((N + 31) / 32) * H;
+  if (head_dim != D) {                                            // generic head dims: gradient of the rotated q; the caller un-rotates (osuf_rope_bwd)
+    if (rope_cos) return OSUF_EUNSUPPORTED;
+    const dim3 grid((nvb + 3) / 4, B);
+    if (gen_dp(head_dim) == 32) hipLaunchKernelGGL(mqa_gen_bwd_dq_kernel<32>, grid, dim3(256), 2 * 64 * 64, stream, a, head_dim);
+    else hipLaunchKernelGGL(mqa_gen_bwd_dq_kernel<128>, grid, dim3(256), 2 * 64 * 256, stream, a, head_dim);
+    return osuf_launch_status();
+  }
   // the pipelined kernel (2 waves/SIMD, 256 VGPRs) wins once the key loop is long: +4.5 % at N=4096, +3 % at 2048, -2 % at <= 1024
   if (variant == OSUF_ATTN_AUTO) variant = N >= 2048 ? OSUF_ATTN_PIPE : OSUF_ATTN_PLAIN;
   if (variant == OSUF_ATTN_PLAIN) hipLaunchKernelGGL(mqa_bwd_dq_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768, stream, a);
@@ -1697,6 +1720,13 @@ extern "C" int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk
       ((rope_cos == nullptr) != (rope_sin == nullptr)) || variant < OSUF_ATTN_AUTO || variant > OSUF_ATTN_PIPE || qsplit < 0 || qsplit > 16)
     return OSUF_EINVAL;
   a.dk = dk; a.dv = dv; a.lddk = lddk; a.g_bf16 = out_dtype == OSUF_DT_BF16; a.rcos = rope_cos; a.rsin = rope_sin;
+  if (head_dim != D) {                                            // generic head dims: gradients of the rotated k and of v, unsplit
+    if (rope_cos) return OSUF_EUNSUPPORTED;
+    const dim3 ggrid(((N + 127) / 128) * B);
+    if (gen_dp(head_dim) == 32) hipLaunchKernelGGL(mqa_gen_bwd_dkv_kernel<32>, ggrid, dim3(256), 2 * 32 * 64 + 256, stream, a, head_dim);
+    else hipLaunchKernelGGL(mqa_gen_bwd_dkv_kernel<128>, ggrid, dim3(256), 2 * 32 * 256 + 256, stream, a, head_dim);
+    return osuf_launch_status();
+  }
   const int b8 = (B + 7) / 8 * 8;
   const dim3 grid(((N + 255) / 256) * b8);
   if (variant == OSUF_ATTN_PLAIN) {
@@ -1763,6 +1793,7 @@ extern "C" int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long l
       ((rope_cos == nullptr) != (rope_sin == nullptr)) || qsplit < 0 || qsplit > 16 || !workspace || !al16(workspace) ||
       !fused_mode_ok(dq_mode) || workspace_bytes < osuf_mqa_bwd_fused_workspace_bytes(B, H, N, out_dtype, qsplit, dq_mode))
     return OSUF_EINVAL;
+  if (head_dim != D) return OSUF_EUNSUPPORTED;                     // the fused sweeps are written for 64-wide heads (others: dq + dkv kernels)
   const bool use512 = fused_use512(B, N, dq_mode);
   if (use512 && (N % 32) != 0) return OSUF_EUNSUPPORTED;           // the 512-key sweep is written for whole 32-query blocks
   a.dk = dk; a.dv = dv; a.lddk = lddk; a.g_bf16 = out_dtype == OSUF_DT_BF16; a.rcos = rope_cos; a.rsin = rope_sin;
@@ -1821,8 +1852,15 @@ extern "C" int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long l
 
 extern "C" int osuf_rope_cast(int dtype, const void* in, long ld_in, void* out, long ld_out, const float* cosb, const float* sinb,
                               int M, int N, int n_rot_heads, int n_heads_total, int head_dim, hipStream_t stream) {
-  if (head_dim != D) return OSUF_EUNSUPPORTED;
+  if (head_dim != D && (head_dim <= 0 || head_dim % 16)) return OSUF_EUNSUPPORTED;
   if (M <= 0 || N <= 0 || M % N || ld_in % 8 || ld_out % 8 || !al16(in) || !al16(out)) return OSUF_EINVAL;
+  if (head_dim != D) {                                            // any head dim that is a multiple of 16: tables [N][head_dim / 2]
+    const int gb = ew_grid((long)M * n_heads_total * (head_dim / 16));
+    if (dtype == OSUF_DT_BF16) hipLaunchKernelGGL((rope_gen_kernel<bf16_t, bf16_t, 1>), dim3(gb), dim3(256), 0, stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, cosb, sinb, M, N, n_rot_heads, n_heads_total, head_dim);
+    else if (dtype == OSUF_DT_F32) hipLaunchKernelGGL((rope_gen_kernel<float, bf16_t, 1>), dim3(gb), dim3(256), 0, stream, (const float*)in, ld_in, (bf16_t*)out, ld_out, cosb, sinb, M, N, n_rot_heads, n_heads_total, head_dim);
+    else return OSUF_EUNSUPPORTED;
+    return osuf_launch_status();
+  }
   const long tot = (long)M * n_heads_total * 4;
   if (dtype == OSUF_DT_BF16) {
     hipLaunchKernelGGL(rope_cast_kernel<bf16_t>, dim3(ew_grid(tot)), dim3(256), 0, stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, cosb, sinb, M, N, n_rot_heads, n_heads_total);
@@ -1834,8 +1872,15 @@ extern "C" int osuf_rope_cast(int dtype, const void* in, long ld_in, void* out, 
 
 extern "C" int osuf_rope_bwd(int dtype, const float* in, long ld_in, void* out, long ld_out, const float* cosb, const float* sinb,
                              int M, int N, int n_rot_heads, int n_heads_total, int head_dim, hipStream_t stream) {
-  if (head_dim != D) return OSUF_EUNSUPPORTED;
+  if (head_dim != D && (head_dim <= 0 || head_dim % 16)) return OSUF_EUNSUPPORTED;
   if (M <= 0 || N <= 0 || M % N || ld_in % 8 || ld_out % 8 || !al16(in) || !al16(out)) return OSUF_EINVAL;
+  if (head_dim != D) {
+    const int gb = ew_grid((long)M * n_heads_total * (head_dim / 16));
+    if (dtype == OSUF_DT_BF16) hipLaunchKernelGGL((rope_gen_kernel<float, bf16_t, -1>), dim3(gb), dim3(256), 0, stream, in, ld_in, (bf16_t*)out, ld_out, cosb, sinb, M, N, n_rot_heads, n_heads_total, head_dim);
+    else if (dtype == OSUF_DT_F32) hipLaunchKernelGGL((rope_gen_kernel<float, float, -1>), dim3(gb), dim3(256), 0, stream, in, ld_in, (float*)out, ld_out, cosb, sinb, M, N, n_rot_heads, n_heads_total, head_dim);
+    else return OSUF_EUNSUPPORTED;
+    return osuf_launch_status();
+  }
   const long tot = (long)M * n_heads_total * 4;
   if (dtype == OSUF_DT_BF16) {
     hipLaunchKernelGGL(rope_bwd_kernel<bf16_t>, dim3(ew_grid(tot)), dim3(256), 0, stream, in, ld_in, (bf16_t*)out, ld_out, cosb, sinb, M, N, n_rot_heads, n_heads_total);

@@ -924,7 +924,7 @@ class AttentionFn(torch.autograd.Function):
         dwo = conv_wgrad(dout, o, wo, "same") if need[5] else None
         dbo = _bias_grad(dout, ctx.bo) if need[6] else None
         wdo = cache.packs(("po", dt), (wo,) if ctx.base is None else (ctx.base[1],), wo, "same", dt)[1]
-        if ops.FUSE_ROWDOT and G == 1:
+        if ops.FUSE_ROWDOT and G == 1 and D == 64:                             # (the epilogue sums 64-column heads)
             do, delta = ops.gemm_nt_rowdot(dout, wdo, o, N, H)                   # dO and sum_d dO * O from one epilogue
         else:
             do, delta = ops.gemm_nt(dout, wdo, None, out_shape=o.shape), None

@@ -25,8 +25,8 @@ class RotaryPositionEmbedding(nn.Module):
 
     def forward(self, q: torch.Tensor, k: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         rt.require_gpu(q)
-        if self.dim != 64:
-            raise NotImplementedError("HIP RoPE kernel is built for head_dim 64")
+        if self.dim % 16:
+            raise NotImplementedError("the HIP RoPE kernel rotates head dims that are multiples of 16")
         cos, sin = Fn.rope_tables(q.shape[-2], self.dim, self.scale_base, q.device, float(self.theta))
         return _rope_bhnd(q, cos, sin), _rope_bhnd(k, cos, sin)
 
@@ -48,8 +48,8 @@ class Attend(nn.Module):
         if attn_mask is not None:
             raise NotImplementedError("the UNet never passes a mask; the HIP kernel has none")
         B, H, N, D = q.shape
-        if D != 64:
-            raise NotImplementedError("HIP attention kernel is built for head_dim 64")
+        if D not in (16, 32, 64, 128):
+            raise NotImplementedError("the HIP attention kernels cover head dims 16, 32, 64 and 128")
         if k.shape[1] not in (1, H) or v.shape[1] != k.shape[1]:
             raise ValueError(f"k / v must carry 1 or {H} heads (got {k.shape[1]} / {v.shape[1]})")
         G = k.shape[1]

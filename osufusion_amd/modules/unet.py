@@ -161,8 +161,8 @@ class Attention(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         rt.require_gpu(x)
-        if self.dim_head != 64:
-            raise NotImplementedError(f"the HIP attention kernels are built for head_dim 64 (got dim_head={self.dim_head})")
+        if self.dim_head not in (16, 32, 64, 128):
+            raise NotImplementedError(f"the HIP attention kernels cover head dims 16, 32, 64 and 128 (got dim_head={self.dim_head})")
         if self.heads % self.kv_heads:
             raise ValueError(f"heads ({self.heads}) must be a multiple of kv_heads ({self.kv_heads})")
         x = rt.cast_rows(x.contiguous(), rt.compute_dtype(self.to_q.weight.dtype))

@@ -425,6 +425,13 @@ def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Ten
     G = kv_heads
     r = H // G
     assert do.dtype == torch.bfloat16 and W == (H + 2 * G) * D and (G == 1 or delta is None)
+    if D != 64:
+        # head dims 16 / 32 / 128 (csrc/attn_generic.hpp): the dQ + dK/dV kernel pair gives the gradients of the ROTATED q / k; the RoPE
+        # transpose is its own pass (the 64-wide kernels fuse it into their epilogues)
+        if cos is not None:
+            raw = mqa_bwd(qkv, o, do, lse, B, N, H, D, scale, torch.float32, None, None, ATTN_AUTO, 0, delta, kv_heads)
+            return rope_bwd(raw, out_dtype, cos, sin, N, H + G, H + 2 * G, D)
+        variant, qsplit = ATTN_AUTO, 0
     dqkv = torch.empty((B, N, W), dtype=out_dtype, device=qkv.device)
     es, ldo_, ldo2 = dqkv.element_size(), _rows(do)[2], _rows(o)[2]
     if delta is None:                                      # (B, H, N) sum_d dO * O: given when the to_out dgrad GEMM produced it

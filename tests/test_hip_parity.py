@@ -511,7 +511,7 @@ def _build_model(case, golden_dir):
     return meta, cfgd, model
 
 
-@pytest.mark.parametrize("case", ["unet_tiny", "unet_mid"])
+@pytest.mark.parametrize("case", ["unet_tiny", "unet_small16", "unet_mid"])      # small16: SURVEY 8c's tiny configuration, attn_dim_head = 16 (attn_generic.hpp)
 def test_unet_vs_golden_fp32(golden_dir, case):
     meta, cfgd, model = _build_model(case, golden_dir)
     net = model.unet

@@ -187,3 +187,90 @@ def test_sampler_error_growth_vs_oracle(golden_dir):
             assert r["hip_vs_oracle"] < 1e-3 * (2 * r["cond_scale"] - 1), r
         # growth: never more than 4x what the oracle itself does to a 3e-4 perturbation (and never below the 1-step bound's scale)
         assert r["hip_vs_oracle"] < max(4.0 * r["oracle_perturbed_3e4_vs_oracle"], 3e-3), r
+
+
+def _attn_case_d(Bn, N, H, D):
+    import torch.nn.functional as F
+    qkv = (torch.randn(Bn, N, (H + 2) * D, device=DEV) * (64 / D) ** 0.25).to(torch.bfloat16)
+    do = torch.randn(Bn, N, H * D).to(torch.bfloat16)
+    qkv32 = qkv.float().cpu().requires_grad_()
+    q = qkv32[..., : H * D].view(Bn, N, H, D).permute(0, 2, 1, 3)
+    k = qkv32[..., H * D: (H + 1) * D][:, None]
+    v = qkv32[..., (H + 1) * D:][:, None]
+    s = (q @ k.transpose(-1, -2)) * D ** -0.5
+    o_ref = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(Bn, N, H * D)
+    o_ref.backward(do.float())
+    return qkv, do.to(DEV), o_ref.detach(), qkv32.grad
+
+
+@pytest.mark.parametrize("D", [16, 32, 128])
+@pytest.mark.parametrize("N", [200, 512])
+def test_attention_head_dims_other_than_64(D, N):
+    """attn_dim_head is a free constructor argument of the reference (unet.py:105-123, diffusion.py:16-30): forward, dQ and dK/dV of the
+    generic-head-dim kernels (csrc/attn_generic.hpp; D = 16 runs zero-padded to 32) against autograd of the fp32 formula
+    (attention.py:87-101), ragged and whole-block lengths, with and without the RoPE transpose pass."""
+    H, Bn = 3, 2
+    qkv, do, o_ref, g_ref = _attn_case_d(Bn, N, H, D)
+    o, lse = ops.mqa_fwd(qkv, Bn, N, H, D, torch.bfloat16, D ** -0.5)
+    e_fwd = rell2(o.float(), o_ref)
+    assert e_fwd < 5e-3, e_fwd
+    ref_lse = torch.logsumexp((qkv.float()[..., : H * D].view(Bn, N, H, D).permute(0, 2, 1, 3) @
+                               qkv.float()[..., H * D: (H + 1) * D][:, None].transpose(-1, -2)) * D ** -0.5, dim=-1) * 1.4426950408889634
+    assert (lse - ref_lse).abs().max().item() < 2e-2
+    dqkv = ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5)
+    for part, sl in (("dq", slice(0, H * D)), ("dk", slice(H * D, (H + 1) * D)), ("dv", slice((H + 1) * D, (H + 2) * D))):
+        e = rell2(dqkv[..., sl], g_ref[..., sl])
+        report(f"attn_generic/D{D}/N{N}/{part}", rel_l2=e)
+        assert e < 1e-2, (part, e)
+    # bf16 output == the rounded fp32 output; the RoPE transpose pass == rotating the raw gradients by hand (attention.py:52-58 transposed)
+    d16 = ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5, torch.bfloat16)
+    assert relmax_(d16.float(), dqkv) < 8e-3
+    cos, sin = Fn.rope_tables(N, D, 2 * N, DEV)
+    got = ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5, torch.float32, cos, sin)
+    want = dqkv.clone()
+    for h in range(H + 1):                                               # q heads and the k head; v untouched
+        y1, y2 = dqkv[..., h * D: h * D + D // 2], dqkv[..., h * D + D // 2: (h + 1) * D]
+        want[..., h * D: h * D + D // 2] = y1 * cos + y2 * sin
+        want[..., h * D + D // 2: (h + 1) * D] = y2 * cos - y1 * sin
+    assert relmax_(got, want) < 1e-5
+    # and the forward rotation + cast
+    rot = ops.rope_cast(qkv, cos, sin, N, H + 1, H + 2, D).float()
+    x = qkv.float()
+    for h in range(H + 1):
+        x1, x2 = x[..., h * D: h * D + D // 2], x[..., h * D + D // 2: (h + 1) * D]
+        assert relmax_(rot[..., h * D: h * D + D // 2], (x1 * cos - x2 * sin).to(torch.bfloat16).float()) < 1e-6
+        assert relmax_(rot[..., h * D + D // 2: (h + 1) * D], (x2 * cos + x1 * sin).to(torch.bfloat16).float()) < 1e-6
+    assert torch.equal(rot[..., (H + 1) * D:], x[..., (H + 1) * D:])
+
+
+def relmax_(a, b):
+    return ((a.float().cpu() - b.float().cpu()).abs().max() / b.float().abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("D,heads,kv_heads", [(16, 4, 1), (32, 4, 2), (128, 2, 1)])
+def test_attention_module_head_dims_vs_oracle(D, heads, kv_heads):
+    """The UNet's Attention block (unet.py:104-146) with 16- / 32- / 128-wide heads, forward and every gradient against the oracle's
+    autograd (fp32 mode; bf16 only where the reference casts)."""
+    from oracle import unet_oracle as O
+    from osufusion_amd.modules.unet import Attention
+    torch.manual_seed(11)
+    C, N, Bn = 64, 96, 2
+    m = Attention(C, D, heads, kv_heads, context_len=192).to(DEV)
+    for p_ in m.parameters():
+        p_.data.normal_(0, 0.15)
+    m.norm.weight.data.add_(1.0)
+    x = torch.randn(Bn, N, C, device=DEV)
+    cfg = O.UNetConfig(attn_dim_head=D, attn_heads=heads, attn_kv_heads=kv_heads)
+    p = {f"a.{k}": v.detach().cpu().clone().requires_grad_() for k, v in m.state_dict().items()}
+    xr = x.cpu().clone().requires_grad_()
+    ref = O.attention(p, "a", xr, cfg, 192, O.Numerics("fp32"))
+    xg = x.clone().requires_grad_()
+    with oa.forced_compute_dtype(torch.float32):
+        got = m(xg)
+    g = torch.randn_like(got)
+    got.backward(g)
+    ref.backward(g.cpu())
+    assert rell2(got, ref) < 5e-3
+    assert rell2(xg.grad, xr.grad) < 2e-2
+    for k, q in m.named_parameters():
+        assert rell2(q.grad, p[f"a.{k}"].grad) < 3e-2, k
