@@ -238,8 +238,8 @@ def test_attention_head_dims_other_than_64(D, N):
     x = qkv.float()
     for h in range(H + 1):
         x1, x2 = x[..., h * D: h * D + D // 2], x[..., h * D + D // 2: (h + 1) * D]
-        assert relmax_(rot[..., h * D: h * D + D // 2], (x1 * cos - x2 * sin).to(torch.bfloat16).float()) < 1e-6
-        assert relmax_(rot[..., h * D + D // 2: (h + 1) * D], (x2 * cos + x1 * sin).to(torch.bfloat16).float()) < 1e-6
+        assert relmax_(rot[..., h * D: h * D + D // 2], (x1 * cos - x2 * sin).to(torch.bfloat16).float()) < 4e-3      # one bf16 ulp (fma contraction)
+        assert relmax_(rot[..., h * D + D // 2: (h + 1) * D], (x2 * cos + x1 * sin).to(torch.bfloat16).float()) < 4e-3
     assert torch.equal(rot[..., (H + 1) * D:], x[..., (H + 1) * D:])
 
 
