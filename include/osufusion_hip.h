@@ -26,6 +26,8 @@ extern "C" {
 
 #define OSUF_DT_F32 0
 #define OSUF_DT_BF16 1
+#define OSUF_DT_F32X3 2   /* osuf_gemm_nt / osuf_gemm_tn only: fp32 storage, every product as three bf16 MFMAs on split operands
+                             (a = bf16(a) + bf16(a - bf16(a)): inputs kept to ~17 bits) -- 3/16 of the cost of the exact-f32 MFMA */
 /* `variant` of the attention-backward entry points: AUTO picks by shape, PLAIN / PIPE force the plain or the software-pipelined kernel */
 #define OSUF_ATTN_AUTO 0
 #define OSUF_ATTN_PLAIN 1

@@ -32,6 +32,7 @@ static_assert(sizeof(osuf_linear_desc) == 56, "osuf_linear_desc is part of the C
 
 #define OSUF_DT_F32 0
 #define OSUF_DT_BF16 1
+#define OSUF_DT_F32X3 2   /* GEMM entry points only: fp32 storage, products as three bf16 MFMAs on split (hi + lo) operands */
 // kernel choice of the attention-backward entry points (per call; nothing is read from the environment)
 #define OSUF_ATTN_AUTO 0
 #define OSUF_ATTN_PLAIN 1

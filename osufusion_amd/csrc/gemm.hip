@@ -160,6 +160,32 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&a
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// fp32 GEMMs as three bf16 MFMAs on split operands ("f32x3", dtype OSUF_DT_F32X3: fp32 storage, a = a_hi + a_lo with a_hi = bf16(a),
+// a_lo = bf16(a - a_hi); a b ~= a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulate).  The dropped a_lo b_lo term and the rounding of
+// the lo parts are 2^-17 relative -- fp32 inputs kept to ~17 bits -- against 2^-9 for plain bf16 operands, at 3/16 of the cost of the
+// exact v_mfma_f32_32x32x2_f32 path (which runs at 1/16 of the bf16 MFMA rate).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split_bf16x8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+  typedef __attribute__((ext_vector_type(8))) float f32x8;
+  f32x8 v, r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = x[i];
+  hi = __builtin_convertvector(v, bf16x8);
+  const u32x4 hb = __builtin_bit_cast(u32x4, hi);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r[2 * i] = x[2 * i] - __uint_as_float(hb[i] << 16);
+    r[2 * i + 1] = x[2 * i + 1] - __uint_as_float(hb[i] & 0xFFFF0000u);
+  }
+  lo = __builtin_convertvector(r, bf16x8);
+}
+__device__ __forceinline__ void mfma_x3(f32x16& acc, const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);      // small terms first
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+
 template <typename T>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[2][2], char* smem, int m0, int n0, int tid, int lane, int wr, int wc) {
   if (g.R == nullptr && g.U == nullptr) gemm_epilogue_impl<T, false>(g, acc, smem, m0, n0, tid, lane, wr, wc);
@@ -291,7 +317,7 @@ __device__ uint4 g_zero_page[4];
 typedef __attribute__((address_space(1))) const void* gas_ptr;
 typedef __attribute__((address_space(3))) void* las_ptr;
 
-template <typename T>
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BK = Mma<T>::BK;
@@ -355,6 +381,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmArgs g) {
     if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
     const char* sa = smem + buf * kStageBytes;
     const char* sb = sa + kTile * 128;
+    if constexpr (SPLIT) {
+      // two 16-deep bf16 k-steps per 32-float stage: lane (r, h) takes the two 16-byte chunks 4 kk + h and 4 kk + 2 + h of its row (any
+      // k order works as long as A and B use the same one)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + swz_off(wr * 64 + i * 32 + lr, 4 * kk + lh));
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(sa + swz_off(wr * 64 + i * 32 + lr, 4 * kk + 2 + lh));
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb + swz_off(wc * 64 + i * 32 + lr, 4 * kk + lh));
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(sb + swz_off(wc * 64 + i * 32 + lr, 4 * kk + 2 + lh));
+          const float xa[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          const float xb[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+          split_bf16x8(xa, ah[i], al[i]);
+          split_bf16x8(xb, bh[i], bl[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mfma_x3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
+      }
+      __syncthreads();
+      continue;
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       u32x4 fa[2], fb[2];
@@ -852,7 +903,7 @@ struct WgradArgs {
 
 // bf16 tile: [64 rows][128 cols] (256 B/row), byte-in-row ^= (row&3)<<6 -> ds_read_b64_tr_b16 conflict-free
 // f32  tile: [32 rows][128 cols] (512 B/row), plain ds_read_b32 (lanes = consecutive columns)
-template <typename T>
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool kBF = sizeof(T) == 2;
@@ -947,6 +998,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs g) {
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    } else if constexpr (SPLIT) {
+      // two 16-deep bf16 k-steps per 32-row stage: lane (r, h) takes rows 16 kk + 8 h .. +7 of its column (one ds_read_b32 each)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float xa[8], xb[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int row = 16 * kk + 8 * lh + e;
+            xa[e] = *reinterpret_cast<const float*>(sy + row * ROWB + (wr * 64 + i * 32 + lr) * 4);
+            xb[e] = *reinterpret_cast<const float*>(sx + row * ROWB + (wc * 64 + i * 32 + lr) * 4);
+          }
+          split_bf16x8(xa, ah[i], al[i]);
+          split_bf16x8(xb, bh[i], bl[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mfma_x3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
       }
     } else {
 #pragma unroll 4
@@ -1454,7 +1527,7 @@ static int gemm_nt_launch(int dtype, const void* A, long lda, const void* W, lon
                           int M, int N, int K, int taps, int Lin, int Lout, int stride, int pad, int mode, int act,
                           float* delta, int heads, hipStream_t stream) {
   const int epc = dtype == OSUF_DT_BF16 ? 8 : 4;
-  if (dtype != OSUF_DT_BF16 && dtype != OSUF_DT_F32) return OSUF_EUNSUPPORTED;
+  if (dtype != OSUF_DT_BF16 && dtype != OSUF_DT_F32 && dtype != OSUF_DT_F32X3) return OSUF_EUNSUPPORTED;
   if (M <= 0 || N <= 0 || K <= 0 || taps <= 0 || Lout <= 0 || Lin <= 0) return OSUF_EINVAL;
   if (M % Lout != 0) return OSUF_EINVAL;
   if (K % epc || lda % epc || ldw % epc || tapstride % epc || N % 4 || ldc % 4) return OSUF_EINVAL;
@@ -1476,6 +1549,7 @@ static int gemm_nt_launch(int dtype, const void* A, long lda, const void* W, lon
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)(gemm_nt_glds_kernel<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   const bool noskinny = getenv("OSUF_GEMM_NOSKINNY") != nullptr;
@@ -1521,6 +1595,7 @@ static int gemm_nt_launch(int dtype, const void* A, long lda, const void* W, lon
     else hipLaunchKernelGGL(gemm_nt_kernel<float>, dim3(grid), dim3(256), lds, stream, g);
   } else {
     if (dtype == OSUF_DT_BF16) hipLaunchKernelGGL(gemm_nt_glds_kernel<bf16_t>, dim3(grid), dim3(256), lds, stream, g);
+    else if (dtype == OSUF_DT_F32X3) hipLaunchKernelGGL((gemm_nt_glds_kernel<float, true>), dim3(grid), dim3(256), lds, stream, g);
     else hipLaunchKernelGGL(gemm_nt_glds_kernel<float>, dim3(grid), dim3(256), lds, stream, g);
   }
   return osuf_launch_status();
@@ -1561,7 +1636,7 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
   if (out_layout == 1) { ldw = (long)N2 * taps; tapstride = 1; es = taps; }
   else if (out_layout != 0) return OSUF_EINVAL;
   const int epc = dtype == OSUF_DT_BF16 ? 8 : 4;
-  if (dtype != OSUF_DT_BF16 && dtype != OSUF_DT_F32) return OSUF_EUNSUPPORTED;
+  if (dtype != OSUF_DT_BF16 && dtype != OSUF_DT_F32 && dtype != OSUF_DT_F32X3) return OSUF_EUNSUPPORTED;
   if (M <= 0 || N1 <= 0 || N2 <= 0 || taps <= 0 || Lout <= 0 || Lin <= 0 || M % Lout) return OSUF_EINVAL;
   if (N1 % epc || N2 % epc || ldy % epc || ldx % epc) return OSUF_EINVAL;
   if (!aligned16(dY) || !aligned16(X)) return OSUF_EINVAL;
@@ -1641,6 +1716,8 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
   const int lds = 4 * 16384;
   if (dtype == OSUF_DT_BF16) {
     hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(tiles, taps, splits), dim3(256), lds, stream, g);
+  } else if (dtype == OSUF_DT_F32X3) {
+    hipLaunchKernelGGL((gemm_tn_kernel<float, true>), dim3(tiles, taps, splits), dim3(256), lds, stream, g);
   } else {
     hipLaunchKernelGGL(gemm_tn_kernel<float>, dim3(tiles, taps, splits), dim3(256), lds, stream, g);
   }

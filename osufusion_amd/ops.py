@@ -42,6 +42,24 @@ def dt_of(t: torch.Tensor) -> int:
     return _DT[t.dtype]
 
 
+F32X3 = 2                  # OSUF_DT_F32X3: fp32 storage, GEMM products as three bf16 MFMAs on split operands
+F32_MATMUL = "exact"       # how the fp32 compute mode multiplies: "exact" (v_mfma_f32_32x32x2_f32, a bitwise fmaf chain, 1/16 of the bf16
+#                            MFMA rate) or "x3" (a = a_hi + a_lo in bf16, three bf16 MFMAs: inputs kept to ~17 bits, 3/16 of the cost)
+
+
+def set_f32_matmul(mode: str) -> str:
+    """-> the previous setting.  Only the conv / linear GEMMs (osuf_gemm_nt / osuf_gemm_tn) have the x3 form; the embedding-sized
+    linears (csrc/skinny.hip), attention (bf16 as the reference casts it) and every norm / elementwise kernel are untouched."""
+    global F32_MATMUL
+    assert mode in ("exact", "x3")
+    prev, F32_MATMUL = F32_MATMUL, mode
+    return prev
+
+
+def gemm_dt(t: torch.Tensor) -> int:
+    return F32X3 if (t.dtype == torch.float32 and F32_MATMUL == "x3") else _DT[t.dtype]
+
+
 class KernelTimer:
     """HIP-event timing of selected C-ABI launches on the stream they run on (bench.py's roofline leg)."""
 
@@ -180,7 +198,7 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
     ldu = _rows(dact)[2] if dact is not None else 0
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() >= N
-    call("osuf_gemm_nt", dt_of(a), _p(a), lda, _p(w3), K, N * K if taps > 1 else 0, _p(out), ldc, _p(pre), ldc, _p(residual), ldr,
+    call("osuf_gemm_nt", gemm_dt(a), _p(a), lda, _p(w3), K, N * K if taps > 1 else 0, _p(out), ldc, _p(pre), ldc, _p(residual), ldr,
          _p(dact), ldu, _p(bias), _p(rscale), _p(stats), M, N, K, taps, lin, lout, stride, pad, mode, act, _stream())
     return (out, pre) if want_pre else out
 
@@ -217,7 +235,7 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, *, taps: int = 1, lin: Optional[i
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == taps * N1 * N2
     need = _lib.load().osuf_gemm_tn_workspace_bytes(dt_of(dy), M, N1, N2, taps)
     ws = _workspace(need, dy.device) if need > 0 else None
-    call("osuf_gemm_tn", dt_of(dy), _p(dy), ldy, _p(x), ldx, _p(out), N2, N1 * N2, M, N1, N2, taps, lin, lout, stride, pad, mode, 0,
+    call("osuf_gemm_tn", gemm_dt(dy), _p(dy), ldy, _p(x), ldx, _p(out), N2, N1 * N2, M, N1, N2, taps, lin, lout, stride, pad, mode, 0,
          1 if conv_layout else 0, 1 if accumulate else 0, _p(ws), need if ws is not None else 0, _stream())
     return out
 

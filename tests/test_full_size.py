@@ -159,8 +159,10 @@ def test_full_size_one_sample_gradient_vs_oracle(full):
                        oracle_at_hip_worst=d_orc[ih], ratio_median=ratio.median())
                 # every parameter's HIP-bf16 error is within 3x the oracle's own bf16-vs-fp32 error on that parameter (floored at 2e-3):
                 # the 0.2 outliers of the table above are parameters on which the reference's autocast is just as far from fp32
-                assert ratio.max() < 3.0, (keys[iw], d_hip[iw].item(), d_orc[iw].item())
-                assert ratio.median() < 1.5, ratio.median()
+                # (measured: worst ratio 1.97, median 0.94; the largest HIP error, 0.204 on an audio-encoder attn.to_q.weight, sits on a
+                #  parameter where the oracle's own bf16 run is 0.211 from its fp32 run)
+                assert ratio.max() < 2.5, (keys[iw], d_hip[iw].item(), d_orc[iw].item())
+                assert ratio.median() < 1.25, ratio.median()
     finally:
         Fn.enable_direct_grads(False)
 

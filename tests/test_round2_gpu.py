@@ -112,7 +112,7 @@ def test_attention_backward_rejects_unknown_variant():
     qkv = torch.zeros(1, 64, 6 * 64, device=DEV, dtype=torch.bfloat16)
     o, lse = ops.mqa_fwd(qkv, 1, 64, 4, 64, torch.bfloat16, 0.125)
     with pytest.raises(RuntimeError, match="invalid argument"):
-        ops.mqa_bwd(qkv, o, o, lse, 1, 64, 4, 64, 0.125, variant=7)
+        ops.mqa_bwd(qkv, o, o, lse, 1, 64, 4, 64, 0.125, variant=99)
 
 
 # ---- clip + AdamW (trainer.py:305-307) -----------------------------------------------------------------------

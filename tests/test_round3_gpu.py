@@ -274,3 +274,79 @@ def test_attention_module_head_dims_vs_oracle(D, heads, kv_heads):
     assert rell2(xg.grad, xr.grad) < 2e-2
     for k, q in m.named_parameters():
         assert rell2(q.grad, p[f"a.{k}"].grad) < 3e-2, k
+
+
+@pytest.mark.parametrize("M,N,K,taps", [(1024, 256, 256, 3), (520, 96, 40, 1), (2048, 768, 512, 1)])
+def test_f32x3_gemms_keep_seventeen_bits(M, N, K, taps):
+    """OSUF_DT_F32X3 (fp32 storage, three bf16 MFMAs on split operands) for the conv / linear GEMMs and their weight gradients against an
+    fp64 product: an order of magnitude and a half inside north_star's 1e-3, two orders better than bf16 operands (residual.py:70,115,
+    unet.py:118-123,149-156 in an fp32 run)."""
+    torch.manual_seed(1)
+    L = M // 2
+    a = torch.randn(M, K, device=DEV)
+    w = torch.randn(taps, N, K, device=DEV) / (K * taps) ** 0.5
+    dy = torch.randn(M, N, device=DEV)
+    kw = dict(taps=taps, lin=L, lout=L, stride=1, pad=taps // 2, mode=0)
+
+    def ref_fwd():
+        ad, wd = a.double().view(2, L, K), w.double()
+        out = torch.zeros(2, L, N, dtype=torch.float64, device=DEV)
+        for t in range(taps):
+            sh = t - taps // 2
+            src = torch.zeros_like(ad)
+            if sh >= 0:
+                src[:, : L - sh] = ad[:, sh:]
+            else:
+                src[:, -sh:] = ad[:, : L + sh]
+            out += src @ wd[t].T
+        return out.view(M, N)
+
+    want = ref_fwd()
+    errs = {}
+    for mode in ("exact", "x3"):
+        prev = ops.set_f32_matmul(mode)
+        try:
+            got = ops.gemm_nt(a, w, None, **kw)
+            gw = ops.gemm_tn(dy, a, **kw)
+        finally:
+            ops.set_f32_matmul(prev)
+        errs[mode] = (rell2(got, want), gw)
+    gw_ref = errs["exact"][1].double()
+    e_w = rell2(errs["x3"][1], gw_ref)
+    bf = ops.gemm_nt(a.to(torch.bfloat16), w.to(torch.bfloat16), None, **kw)
+    e_bf = rell2(bf.float(), want)
+    report(f"f32x3/M{M}N{N}K{K}t{taps}", exact=errs["exact"][0], x3=errs["x3"][0], bf16=e_bf, wgrad_x3_vs_exact=e_w)
+    assert errs["exact"][0] < 2e-6
+    assert errs["x3"][0] < 3e-5 and e_w < 3e-5, (errs["x3"][0], e_w)
+    assert e_bf > 30 * errs["x3"][0]
+
+
+def test_f32x3_mode_unet_vs_golden(golden_dir):
+    """The whole UNet in the fp32 compute mode with x3 GEMMs against the reference's golden (north_star: 1e-3), next to the exact mode."""
+    from osufusion_amd.pattern import synth_inputs
+    from tests.test_hip_parity import G, _build_model
+    meta, cfgd, model = _build_model("unet_mid", golden_dir)
+    g = G(golden_dir, "unet_mid")
+    x, a, c, t, noise = (T(v) for v in synth_inputs("unet_mid", meta["B"], meta["L"]))
+    out = {}
+    for mode in ("exact", "x3"):
+        prev = ops.set_f32_matmul(mode)
+        try:
+            with torch.no_grad(), oa.forced_compute_dtype(torch.float32):
+                out[mode] = rell2(model.unet(x, a, t, c, cond_drop_prob=0.0), g["y_cond"])
+            for q in model.parameters():
+                q.grad = None
+            with oa.forced_compute_dtype(torch.float32):
+                loss = model.loss_with(x, a, c, noise, t, cond_drop_prob=0.0)
+                loss.backward()
+            out[mode + "_loss"] = abs(loss.item() - float(g["loss"])) / abs(float(g["loss"]))
+            params = dict(model.unet.named_parameters())
+            import numpy as np
+            gn = np.array([params[k].grad.norm().item() for k in meta["param_names"]])
+            ref = g["grad_norms"]
+            out[mode + "_gn"] = float((np.abs(gn - ref) / (ref + 1e-3 * ref.max())).max())
+        finally:
+            ops.set_f32_matmul(prev)
+    report("f32x3/unet_mid_vs_golden", **out)
+    assert out["x3"] < 1e-3 and out["exact"] < 1e-3
+    assert out["x3_loss"] < 1e-3 and out["x3_gn"] < 2e-2
