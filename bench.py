@@ -169,6 +169,8 @@ def main() -> None:
     ap.add_argument("--attn-bwd", choices=["auto", "pair", "fused", "fused256", "fused512", "slabs"], default="auto",
                     help="attention backward: auto = the library default (fused sweep, atomic dQ, 256 or 512 keys per workgroup by shape); "
                          "fused256 / fused512 = force that sweep (A/B); pair = dQ + dK/dV kernels; slabs = fused, fixed-order dQ")
+    ap.add_argument("--timed-mode", choices=["bf16", "fp32x3", "fp32"], default="bf16",
+                    help="profiling only: run the TIMED region in an fp32 compute mode (the headline metric is bf16; such a line is labelled)")
     ap.add_argument("--no-fuse-rowdot", action="store_true", help="A/B: sum(dO*O) by the stand-alone pass instead of the to_out dgrad epilogue")
     args = ap.parse_args()
 
@@ -203,7 +205,10 @@ def main() -> None:
     if args.attn_bwd != "auto":
         ops.ATTN_BWD_DEFAULT = {"fused": ops.ATTN_FUSED, "slabs": ops.ATTN_FUSED_SLABS, "pair": ops.ATTN_AUTO, "fused256": ops.ATTN_FUSED256,
                                 "fused512": ops.ATTN_FUSED512}[args.attn_bwd]
-    trainer = Trainer(model, lr=1e-4, weight_decay=1e-2, clip_grad_norm=1.0, compute_dtype=torch.bfloat16)
+    trainer = Trainer(model, lr=1e-4, weight_decay=1e-2, clip_grad_norm=1.0,
+                      compute_dtype=torch.bfloat16 if args.timed_mode == "bf16" else torch.float32)
+    if args.timed_mode == "fp32x3":
+        ops.set_f32_matmul("x3")
     x, a, c, noise, t = synth_batch(rank, device, args.batch, args.length)
 
     def sync():
@@ -273,7 +278,10 @@ def main() -> None:
             "loss": round(loss.item(), 5), "grad_norm": round(gnorm.item(), 4),
             "roofline": roof,
         }
-        if world == 1 and not args.no_fp32_mode and not args.lora and full:
+        if args.timed_mode != "bf16":
+            out["metric"] += f" [PROFILING RUN in the {args.timed_mode} compute mode -- not the headline number]"
+            out["dtype"] = args.timed_mode
+        if world == 1 and not args.no_fp32_mode and not args.lora and full and args.timed_mode == "bf16":
             # the compute mode in which north_star's 1e-3 bound holds (exact-f32 MFMA everywhere, bf16 only where the reference casts):
             # one warm-up + one timed step, after the timed region; bf16 (timed above) sits at the reference's own autocast distance
             trainer.compute_dtype = torch.float32

@@ -212,7 +212,7 @@ def gemm_nt_rowdot(a: torch.Tensor, w: torch.Tensor, o: torch.Tensor, L: int, he
     assert Mo == M and No == heads * 64 and o.dtype == a.dtype and M % L == 0
     out = torch.empty(o.shape, dtype=a.dtype, device=a.device)
     delta = torch.empty((M // L, heads, L), dtype=torch.float32, device=a.device)
-    call("osuf_gemm_nt_rowdot", dt_of(a), _p(a), lda, _p(w3), K, _p(out), heads * 64, _p(o), ldo, _p(delta), M, heads * 64, K, L, heads, _stream())
+    call("osuf_gemm_nt_rowdot", gemm_dt(a), _p(a), lda, _p(w3), K, _p(out), heads * 64, _p(o), ldo, _p(delta), M, heads * 64, K, L, heads, _stream())
     return out, delta
 
 
