@@ -1306,7 +1306,8 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512_kernel(AttnArgs a, fl
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { qa[ks] = lds_row_frag(qs, lo, ks, 0); da[ks] = lds_row_frag(dos, lo, ks, 0); }
     read_consts_s(); read_consts_dp();
-    kf[0] = lds_row_frag(kimg + wave * 4 * 4096, lo, 0, 0); kf[1] = lds_row_frag(kimg + wave * 4 * 4096, lo, 1, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = lds_row_frag(kimg + wave * 4 * 4096, lo, ks, 0);
     DqOps o0 = dq_read(ep, 0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -1338,38 +1339,42 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512_kernel(AttnArgs a, fl
       // slot = one matrix instruction (or a dQ pair), then the fillers that issue while it executes; OSUF_FENCE pins the order.
       // Fragment reads sit as late as their consumers allow (two slots ahead or more): the register file is full
       const char* krow = kimg + (wave * 4 + t) * 4096;
-      // dQ k-steps: tiles 0-2 run theirs in slots 2, 9, 16, 17; the last tile runs them early (slots 2, 6, 9, 10) so that the eight float
-      // atomics of the finished tiles can leave one or two per slot behind its dV / dK MFMAs instead of as one burst before the barrier
-      constexpr bool kLast = false;
+      // dQ k-steps: tiles 0-2 run theirs in slots 2, 9, 12, 16; the last tile runs them early (slots 2, 6, 9, 10) so that the eight float
+      // atomics of the finished tiles can leave two per slot behind its dK MFMAs instead of as one burst before the barrier.  Every
+      // operand read sits at least three slots ahead of its consumer.
       const bool last = t == 3;
       OSUF_FENCE;
-      mfma32_vgpr(s, qa[0], kf[0]);                 OSUF_FENCE;  o1 = dq_read(ep, 4 * t + 1); kf[2] = lds_row_frag(krow, lo, 2, 0); kf[3] = lds_row_frag(krow, lo, 3, 0);  OSUF_FENCE;
+      mfma32_vgpr(s, qa[0], kf[0]);                 OSUF_FENCE;  o1 = dq_read(ep, 4 * t + 1);                                   OSUF_FENCE;
       mfma32_vgpr(s, qa[1], kf[1]);                 OSUF_FENCE;
       if (t == 0) { mfma16_vgpr_first(acc0, o0.av0, o0.bv); mfma16_vgpr_first(acc1, o0.av1, o0.bv); } else dq_mma(o0);          OSUF_FENCE;   // k-step 4t
       mfma32_vgpr(s, qa[2], kf[2]);                 OSUF_FENCE;  trd[0][0] = lds_tr_frag(dos, lo, 0, 0); trd[0][1] = lds_tr_frag(dos, lo, 0, 1);   OSUF_FENCE;
       mfma32_vgpr(s, qa[3], kf[3]);                 OSUF_FENCE;  o0 = dq_read(ep, 4 * t + 2);                                   OSUF_FENCE;
       mfma32_vgpr(dp, da[0], vf[t][0]);             OSUF_FENCE;  trd[1][0] = lds_tr_frag(dos, lo, 16, 0); trd[1][1] = lds_tr_frag(dos, lo, 16, 1); OSUF_FENCE;
-      mfma32_vgpr(dp, da[1], vf[t][1]);             OSUF_FENCE;  if (last) { dq_mma(o1); o1 = dq_read(ep, 15); }                OSUF_FENCE;   // (last tile: k-step 13)
-      mfma32_vgpr(dp, da[2], vf[t][2]);             OSUF_FENCE;  mfma32_fence_short(s); exp4(0);                                OSUF_FENCE;
+      mfma32_vgpr(dp, da[1], vf[t][1]);             OSUF_FENCE;  if (last) dq_mma(o1);                                          OSUF_FENCE;   // (last tile: k-step 13)
+      mfma32_vgpr(dp, da[2], vf[t][2]);             OSUF_FENCE;  mfma32_fence_short(s); exp4(0); if (last) o1 = dq_read(ep, 15); OSUF_FENCE;
       mfma32_vgpr(dp, da[3], vf[t][3]);             OSUF_FENCE;  exp4(4);                                                       OSUF_FENCE;
       if (last) dq_mma(o0); else dq_mma(o1);        OSUF_FENCE;  pf[0] = acc_to_frag(s, 0); OSUF_FENCE; exp4(8);                OSUF_FENCE;   // k-step 4t+1 (last tile: 14)
-      mfma32_agpr_nop(dv[t][0], trd[0][0], pf[0]);  OSUF_FENCE;  exp4(12); if (last) dq_mma(o1);                                OSUF_FENCE;   // (last tile: k-step 15)
+      mfma32_agpr_nop(dv[t][0], trd[0][0], pf[0]);  OSUF_FENCE;  exp4(12); if (last) dq_mma(o1); else o1 = dq_read(ep, 4 * t + 3);   OSUF_FENCE;   // (last tile: k-step 15)
       mfma32_agpr(dv[t][1], trd[0][1], pf[0]);      OSUF_FENCE;  pf[1] = acc_to_frag(s, 1); OSUF_FENCE; mfma32_fence_short(dp); ds4(0);
                                                                  trq[0][0] = lds_tr_frag(qs, lo, 0, 0); trq[0][1] = lds_tr_frag(qs, lo, 0, 1);     OSUF_FENCE;
-      mfma32_agpr(dv[t][0], trd[1][0], pf[1]);      OSUF_FENCE;  ds4(4); ds4(8); if (last) mfma16_fence(acc0, acc1);            OSUF_FENCE;
+      mfma32_agpr(dv[t][0], trd[1][0], pf[1]);      OSUF_FENCE;  ds4(4); ds4(8); if (last) mfma16_fence(acc0, acc1); else dq_mma(o0);   OSUF_FENCE;   // k-step 4t+2
       mfma32_agpr(dv[t][1], trd[1][1], pf[1]);      OSUF_FENCE;  ds4(12); df[0] = acc_to_frag(dp, 0); OSUF_FENCE;
-                                                                 trq[1][0] = lds_tr_frag(qs, lo, 16, 0); trq[1][1] = lds_tr_frag(qs, lo, 16, 1);   OSUF_FENCE;
-      // (the next tile's first operands -- initial accumulators, K fragments 0 and 1 -- are read three slots ahead of its first MFMA)
+                                                                 trq[1][0] = lds_tr_frag(qs, lo, 16, 0); trq[1][1] = lds_tr_frag(qs, lo, 16, 1);
+                                                                 if (!last) o0 = dq_read(ep, 4 * t + 4);                        OSUF_FENCE;
       mfma32_agpr(dk[t][0], trq[0][0], df[0]);      OSUF_FENCE;  df[1] = acc_to_frag(dp, 1); OSUF_FENCE; ds_write2(0);
                                                                  if (last) dq_add2(acc0, acc1, 0, ph, ppb); else read_consts_s();                   OSUF_FENCE;
       mfma32_agpr(dk[t][1], trq[0][1], df[0]);      OSUF_FENCE;  ds_write2(2);
-                                                                 if (last) dq_add2(acc0, acc1, 1, ph, ppb); else { o1 = dq_read(ep, 4 * t + 3); read_consts_dp(); }   OSUF_FENCE;
+                                                                 if (last) dq_add2(acc0, acc1, 1, ph, ppb); else read_consts_dp();                  OSUF_FENCE;
       mfma32_agpr(dk[t][0], trq[1][0], df[1]);      OSUF_FENCE;
       if (last) dq_add2(acc0, acc1, 2, ph, ppb);
-      else { dq_mma(o0); kf[0] = lds_row_frag(krow + 4096, lo, 0, 0); kf[1] = lds_row_frag(krow + 4096, lo, 1, 0); }                                OSUF_FENCE;   // k-step 4t+2
+      else {
+        dq_mma(o1);                                                                                                                           // k-step 4t+3
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[ks] = lds_row_frag(krow + 4096, lo, ks, 0);
+      }
+      OSUF_FENCE;
       mfma32_agpr(dk[t][1], trq[1][1], df[1]);      OSUF_FENCE;
-      if (last) dq_add2(acc0, acc1, 3, ph, ppb); else { dq_mma(o1); o0 = dq_read(ep, 4 * t + 4); }                                                                // k-step 4t+3
-      (void)kLast;
+      if (last) dq_add2(acc0, acc1, 3, ph, ppb);
     }
     OSUF_FENCE;
     store_stage((it + 1) & 1);                                     // (after the last pair: a stage nobody reads)
