@@ -1224,9 +1224,13 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512_kernel(AttnArgs a, fl
   // a wave-uniform 64-bit base + a 32-bit per-lane BYTE offset (the saddr form): eight zero-extended 64-bit lane offsets would not fit the file
   const unsigned aoffb = (unsigned)((4 * g4) * (a.H * D) + wave * 16 + ip) * 4u;
   const unsigned rowb = (unsigned)(a.H * D) * 4u;
-  auto dq_add2 = [&](const f32x4& q0, const f32x4& q1, int r, int ph_, int ppb_) {      // row r of both query halves
+  // wave-uniform base of the PREVIOUS pair's dQ rows, carried from iteration to iteration (re-deriving it from (b, block, head) for each of
+  // the four atomic pairs was ~40 scalar instructions per iteration in a loop that is bound by its instruction count)
+  char* dq_prev = reinterpret_cast<char*>(dq32 + ((long)b * a.N + qb_begin * 32) * (a.H * D));
+  char* dq_cur = dq_prev;
+  auto dq_add2 = [&](const f32x4& q0, const f32x4& q1, int r, int, int) {      // row r of both query halves
     if constexpr (ATOMICS) {
-      char* sb = reinterpret_cast<char*>(dq32 + ((long)b * a.N + ppb_ * 32) * (a.H * D) + ph_ * D);      // scalar
+      char* sb = dq_prev;
       unsigned ob = aoffb;
       asm volatile("" : "+v"(ob));
       atomic_add_f32(reinterpret_cast<float*>(sb + (ob + (unsigned)r * rowb)), q0[r]);
@@ -1235,9 +1239,9 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512_kernel(AttnArgs a, fl
       asm volatile("" :: "v"(q0[r]), "v"(q1[r]));
     }
   };
-  auto dq_add = [&](const f32x4& q0, const f32x4& q1, int ph_, int ppb_) {
+  auto dq_add = [&](const f32x4& q0, const f32x4& q1, int, int) {
     if constexpr (ATOMICS) {
-      char* sb = reinterpret_cast<char*>(dq32 + ((long)b * a.N + ppb_ * 32) * (a.H * D) + ph_ * D);      // scalar
+      char* sb = dq_prev;
       unsigned ob = aoffb;
       asm volatile("" : "+v"(ob));                                  // opaque per call: keeps the eight offsets out of loop-invariant registers
 #pragma unroll
@@ -1380,7 +1384,9 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512_kernel(AttnArgs a, fl
     store_stage((it + 1) & 1);                                     // (after the last pair: a stage nobody reads)
     __syncthreads();
     ph = ch; ppb = cpb;
-    if (++ch == a.H) { ch = 0; ++cpb; }
+    dq_prev = dq_cur;
+    if (++ch == a.H) { ch = 0; ++cpb; dq_cur += (32L * a.H - (a.H - 1)) * (D * 4); }
+    else dq_cur += D * 4;
   }
 #undef OSUF_FENCE
   {                                                                // dQ of the last pair
