@@ -140,6 +140,13 @@ int osuf_rope_bwd(int dtype, const float* in, long ld_in, void* out, long ld_out
  * q/k/v/dout are bf16; o is written bf16-rounded in o_dtype; lse2 = log2-domain logsumexp [B][H][N]. */
 int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
                  float* lse2, int B, int H, int N, int head_dim, float scale, hipStream_t stream);
+/* Attend(q, k, v, attn_mask) (attention.py:77-99): the reference casts the mask to bf16 and passes it to SDPA as an additive bias of
+ * the scaled scores (so a bool mask adds 1.0 / 0.0 -- kept).  mask: bf16, element strides over (batch, head, query, key), 0 for a
+ * broadcast dimension.  Inference only (no backward entry point); all head dims go through the generic kernel.
+ * replaces: F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask) at attention.py:94-99. */
+int osuf_mqa_fwd_masked(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
+                        float* lse2, const void* mask, long mask_b, long mask_h, long mask_q, long mask_k, int B, int H, int N,
+                        int head_dim, float scale, hipStream_t stream);
 int osuf_attn_delta(const void* dout, long lddo, const void* o, long ldo, int o_dtype, float* delta, int B, int H, int N,
                     int head_dim, hipStream_t stream);
 /* dq / dk / dv are written in out_dtype (OSUF_DT_F32 or OSUF_DT_BF16).  rope_cos / rope_sin ([N][32] fp32, or both NULL): q and k

@@ -118,6 +118,7 @@ struct AttnArgs {
   float scale;
   int qsplit;                                   // dK/dV: > 1 = the query range is cut into qsplit parts (short sequences: more workgroups),
   float* wsk; float* wsv;                       //        per-part partial sums in [qsplit][B*N][64] workspaces, summed by dkv_finish_kernel
+  const bf16_t* mask; long mask_b, mask_h, mask_q, mask_k;   // osuf_mqa_fwd_masked: additive bf16 score bias, element strides (0 = broadcast)
 };
 
 // cooperative K/V tile stage: NT threads move one 64-key tile (64 x 128 B of K and of V = 512 + 512 16-B chunks)
@@ -1636,6 +1637,27 @@ extern "C" int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, co
     return osuf_launch_status();
   }
   hipLaunchKernelGGL(mqa_fwd_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768 + 8 * 4096, stream, a);
+  return osuf_launch_status();
+}
+
+// Attend(q, k, v, attn_mask) (attention.py:77-99): the forward with an additive bf16 score bias, element strides over (b, h, q, key) with 0
+// for broadcast dimensions.  Inference path of the stand-alone Attend module; every head dim (64 included) runs the generic kernel.
+extern "C" int osuf_mqa_fwd_masked(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
+                                   float* lse2, const void* mask, long mask_b, long mask_h, long mask_q, long mask_k, int B, int H, int N,
+                                   int head_dim, float scale, hipStream_t stream) {
+  if (head_dim != D && !gen_dp(head_dim)) return OSUF_EUNSUPPORTED;
+  if (B <= 0 || H <= 0 || N <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || !al16(q) || !al16(k) || !al16(v) || !al16(o) || !mask || scale == 0.f)
+    return OSUF_EINVAL;
+  AttnArgs a = {};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
+  a.o = o; a.ldo = ldo; a.o_is_f32 = o_dtype == OSUF_DT_F32; a.lse2 = lse2; a.B = B; a.H = H; a.N = N; a.scale = scale;
+  a.mask = (const bf16_t*)mask; a.mask_b = mask_b; a.mask_h = mask_h; a.mask_q = mask_q; a.mask_k = mask_k;
+  const int nvb = ((N + 31) / 32) * H;
+  const dim3 grid((nvb + 3) / 4, B);
+  const int dp = head_dim == D ? 64 : gen_dp(head_dim);
+  if (dp == 32) hipLaunchKernelGGL((mqa_gen_fwd_kernel<32, true>), grid, dim3(256), 2 * 64 * 64, stream, a, head_dim);
+  else if (dp == 64) hipLaunchKernelGGL((mqa_gen_fwd_kernel<64, true>), grid, dim3(256), 2 * 64 * 128, stream, a, head_dim);
+  else hipLaunchKernelGGL((mqa_gen_fwd_kernel<128, true>), grid, dim3(256), 2 * 64 * 256, stream, a, head_dim);
   return osuf_launch_status();
 }
 

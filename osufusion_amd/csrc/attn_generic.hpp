@@ -68,8 +68,10 @@ __device__ __forceinline__ void gen_store_row(void* base, long elem_off, int is_
     }
 }
 
-// ---- forward (attention.py:94-99 under unet.py:125-141): 4 waves = 4 (head, 32-query block) pairs share each 64-key K / V tile
-template <int DP>
+// ---- forward (attention.py:94-99 under unet.py:125-141): 4 waves = 4 (head, 32-query block) pairs share each 64-key K / V tile.
+// MASKED: Attend's attn_mask (attention.py:77-99) -- the reference casts it to bf16 and hands it to SDPA as an ADDITIVE bias of the
+// scaled scores (a bool mask therefore adds 1.0 / 0.0; that is the reference's behaviour and is kept), broadcast over (B, H, N, N).
+template <int DP, bool MASKED = false>
 __global__ __launch_bounds__(256) void mqa_gen_fwd_kernel(AttnArgs a, int hd) {
   using T = GenTile<DP>;
   extern __shared__ __attribute__((aligned(16))) char smem[];        // K image 64 x RB | V image 64 x RB
@@ -110,11 +112,16 @@ __global__ __launch_bounds__(256) void mqa_gen_fwd_kernel(AttnArgs a, int hd) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = j * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if constexpr (MASKED) {                                        // bias in units of the scaled score: s is the raw dot product
+          if (qok && key < a.N)
+            s[kt][r] += bf16_to_f32(a.mask[(long)b * a.mask_b + (long)h * a.mask_h + (long)qrow * a.mask_q + (long)key * a.mask_k]) / a.scale;
+        }
         if (key >= a.N) s[kt][r] = -INFINITY;
         mx = fmaxf(mx, s[kt][r]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
-    const float m_new = fmaxf(m_run, mx);                             // (a tile always holds >= 1 valid key: m_new is finite)
+    float m_new = fmaxf(m_run, mx);                                   // (unmasked: a tile always holds >= 1 valid key, m_new is finite)
+    if constexpr (MASKED) m_new = m_new == -INFINITY ? -3.0e38f : m_new;   // a row whose keys so far are all masked with -inf: p = 0, no NaN
     const float alpha = fast_exp2(m_run - m_new);
     m_run = m_new;
     l_run *= alpha;

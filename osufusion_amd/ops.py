@@ -424,6 +424,20 @@ def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.
     return o, lse
 
 
+def mqa_fwd_masked(qkv: torch.Tensor, mask4: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.dtype, scale: float) -> torch.Tensor:
+    """Attend with attn_mask (attention.py:77-99): mask4 = the bf16 mask expanded (as a view: stride 0 on broadcast dims) to (B, H, N, N);
+    one K/V head (G = 1) -- the caller repeats K / V heads itself as the reference's Attention does."""
+    M, W, ld = _rows(qkv)
+    assert qkv.dtype == torch.bfloat16 and W == (H + 2) * D and mask4.dtype == torch.bfloat16 and tuple(mask4.shape) == (B, H, N, N)
+    o = torch.empty((B, N, H * D), dtype=out_dtype, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    base = qkv.data_ptr()
+    sb, sh, sq, sk = mask4.stride()
+    call("osuf_mqa_fwd_masked", base, ld, base + 2 * H * D, ld, base + 2 * (H + 1) * D, ld, o.data_ptr(), H * D, _DT[out_dtype], lse.data_ptr(),
+         mask4.data_ptr(), sb, sh, sq, sk, B, H, N, D, scale, _stream())
+    return o
+
+
 ATTN_AUTO, ATTN_PLAIN, ATTN_PIPE, ATTN_FUSED, ATTN_FUSED_SLABS = 0, 1, 2, 3, 4
 ATTN_FUSED256, ATTN_FUSED512, ATTN_FUSED512_TIMING = 5, 6, 7     # force the 256- / 512-key sweep of ATTN_FUSED; 512 without atomics (timing only)
 _FUSED_DQ_MODE = {ATTN_FUSED: 0, ATTN_FUSED_SLABS: 1, ATTN_FUSED256: 2, ATTN_FUSED512: 3, ATTN_FUSED512_TIMING: 4}      # OSUF_DQ_*

@@ -350,3 +350,37 @@ def test_f32x3_mode_unet_vs_golden(golden_dir):
     report("f32x3/unet_mid_vs_golden", **out)
     assert out["x3"] < 1e-3 and out["exact"] < 1e-3
     assert out["x3_loss"] < 1e-3 and out["x3_gn"] < 2e-2
+
+
+@pytest.mark.parametrize("D,H,G", [(64, 4, 1), (16, 2, 2), (128, 2, 1)])
+def test_attend_with_mask_matches_reference_semantics(D, H, G):
+    """Attend(q, k, v, attn_mask) (attention.py:77-99): the reference casts the mask to bf16 and passes it to SDPA, i.e. it is an ADDITIVE
+    bias of the scaled scores whatever its dtype was (a bool mask adds 1.0 / 0.0).  Checked against that formula in fp32 on the
+    bf16-cast inputs: a float bias incl. -inf blocks (broadcast over batch and heads), a per-head bias, and a bool mask."""
+    from osufusion_amd.modules.attention import Attend
+    torch.manual_seed(4)
+    B, N = 2, 200
+    q = torch.randn(B, H, N, D, device=DEV)
+    k = torch.randn(B, G, N, D, device=DEV)
+    v = torch.randn(B, G, N, D, device=DEV)
+    att = Attend()
+
+    def ref(mask):
+        qb, kb, vb = (t.to(torch.bfloat16).float() for t in (q, k, v))
+        if G != H:
+            kb, vb = kb.expand(B, H, N, D), vb.expand(B, H, N, D)
+        sc = (qb @ kb.transpose(-1, -2)) * D ** -0.5 + mask.to(torch.bfloat16).float()
+        return sc.softmax(-1) @ vb
+
+    causal = torch.zeros(N, N, device=DEV).masked_fill(torch.triu(torch.ones(N, N, device=DEV, dtype=torch.bool), 1), float("-inf"))
+    per_head = torch.randn(1, H, N, N, device=DEV) * 2
+    boolean = torch.rand(B, 1, N, N, device=DEV) > 0.5
+    for name, m in (("causal -inf", causal), ("per-head float", per_head), ("bool", boolean)):
+        if G == H and G > 1 and m.dim() == 4 and m.shape[1] == 1:
+            pass
+        got = att(q, k, v, attn_mask=m)
+        want = ref(m)
+        e = rell2(got, want)
+        report(f"attend_mask/D{D}/{name}", rel_l2=e)
+        assert torch.isfinite(got).all() and e < 6e-3, (name, e)
+    assert rell2(att(q, k, v), ref(torch.zeros(1, device=DEV))) < 6e-3
