@@ -84,7 +84,8 @@ def test_two_rank_gradient_matches_single_process():
 
 
 @pytest.mark.timeout(600)
-def test_bench_main_with_two_ranks(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])                    # (the box admits 6 GPU processes: this test + 4 ranks)
+def test_bench_main_with_ranks(tmp_path, world):
     """bench.py's world > 1 branch (process-group init, per-rank data, barrier-bracketed timing, MAX over ranks, rank-0 JSON line)
     launched exactly as the driver launches it -- `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` -- on this
     one-GPU box: gloo transport and both ranks on cuda:0 (OSUF_DIST_BACKEND / OSUF_SINGLE_DEVICE rehearsal knobs), a small UNet.
@@ -94,18 +95,18 @@ def test_bench_main_with_two_ranks(tmp_path):
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     env = dict(os.environ, OSUF_DIST_BACKEND="gloo", OSUF_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "2",
            "--dim-h", "96", "--length", "256", "--batch", "2"]
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=540)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                    # ONE line, from rank 0
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 2 and out["scaling"] == "weak"
-    assert out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 4
+    assert out["n_gpus"] == world and out["steps"] == 2 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"] == f"dp{world}" and out["config"]["global_batch"] == 2 * world
     assert out["value"] > 0 and out["ms_per_step"] > 0 and out["higher_is_better"] is True
-    assert abs(out["value"] - 2 * 2 / (out["ms_per_step"] * 2 / 1e3) * (2 / 32)) < 1e-2 * out["value"] + 1e-3     # whole-job aggregate, in B=32 steps
+    assert abs(out["value"] - world * 2 / (out["ms_per_step"] * 2 / 1e3) * (2 / 32)) < 1e-2 * out["value"] + 1e-3     # whole-job aggregate, in B=32 steps
     assert "cpu_baseline" not in out and "secondary" not in out  # single-GPU legs only
     import math
     assert math.isfinite(out["loss"]) and math.isfinite(out["grad_norm"])
