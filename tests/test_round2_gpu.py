@@ -187,8 +187,10 @@ def test_attend_module_vs_sdpa(N):
     got = Attend()(q, kh, vh)
     want = F.scaled_dot_product_attention(qb, kh.to(torch.bfloat16).float().cpu(), vh.to(torch.bfloat16).float().cpu()).to(torch.bfloat16).float()
     assert rell2(got, want) < 5e-3 and relmax(got, want) < 1.5e-2
-    with pytest.raises(NotImplementedError):
-        Attend()(q, k, v, attn_mask=torch.ones(N, N, device=DEV, dtype=torch.bool))
+    # attn_mask (round 3, tests/test_round3_gpu.py): the reference's cast-to-bf16-and-add semantics -- an all-True bool mask adds 1.0 to every
+    # score, which the softmax ignores
+    ones = Attend()(q, k1, v1, attn_mask=torch.ones(N, N, device=DEV, dtype=torch.bool))
+    assert rell2(ones, Attend()(q, k1, v1)) < 5e-3
 
 
 def test_set_full_bf16_switches_every_kernel_to_bf16(golden_dir):
