@@ -99,23 +99,33 @@ __global__ __launch_bounds__(256) void mqa_gen_fwd_kernel(AttnArgs a, int hd) {
     T::fill(smem + TILE, a.v + (long)b * a.N * a.ldv, a.ldv, 64, j * 64, a.N, hd, tid, 256);
     __syncthreads();
     f32x16 s[2];
+    if constexpr (MASKED) {                                            // the bias starts the accumulator, in units of the raw dot product
+      // (loads issued ahead of the MFMAs; indices clamped instead of branched on: rows / keys past N are discarded below)
+      const bf16_t* mrow = a.mask + (long)b * a.mask_b + (long)h * a.mask_h + (long)(qok ? qrow : 0) * a.mask_q;
+      const float inv_scale = 1.f / a.scale;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+          const int key = j * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          s[kt][r] = bf16_to_f32(mrow[(long)(key < a.N ? key : a.N - 1) * a.mask_k]) * inv_scale;
+        }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int ks = 0; ks < T::KS; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(T::row_frag(smem, lane, ks, kt), qf[ks], s[kt], 0, 0, 0);
-    }
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = j * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if constexpr (MASKED) {                                        // bias in units of the scaled score: s is the raw dot product
-          if (qok && key < a.N)
-            s[kt][r] += bf16_to_f32(a.mask[(long)b * a.mask_b + (long)h * a.mask_h + (long)qrow * a.mask_q + (long)key * a.mask_k]) / a.scale;
-        }
         if (key >= a.N) s[kt][r] = -INFINITY;
         mx = fmaxf(mx, s[kt][r]);
       }

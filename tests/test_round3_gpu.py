@@ -352,7 +352,7 @@ def test_f32x3_mode_unet_vs_golden(golden_dir):
     assert out["x3_loss"] < 1e-3 and out["x3_gn"] < 2e-2
 
 
-@pytest.mark.parametrize("D,H,G", [(64, 4, 1), (16, 2, 2), (128, 2, 1)])
+@pytest.mark.parametrize("D,H,G", [(64, 4, 1), (16, 2, 2), (32, 3, 1), (128, 2, 1)])
 def test_attend_with_mask_matches_reference_semantics(D, H, G):
     """Attend(q, k, v, attn_mask) (attention.py:77-99): the reference casts the mask to bf16 and passes it to SDPA, i.e. it is an ADDITIVE
     bias of the scaled scores whatever its dtype was (a bool mask adds 1.0 / 0.0).  Checked against that formula in fp32 on the
@@ -376,11 +376,35 @@ def test_attend_with_mask_matches_reference_semantics(D, H, G):
     per_head = torch.randn(1, H, N, N, device=DEV) * 2
     boolean = torch.rand(B, 1, N, N, device=DEV) > 0.5
     for name, m in (("causal -inf", causal), ("per-head float", per_head), ("bool", boolean)):
-        if G == H and G > 1 and m.dim() == 4 and m.shape[1] == 1:
-            pass
         got = att(q, k, v, attn_mask=m)
         want = ref(m)
         e = rell2(got, want)
         report(f"attend_mask/D{D}/{name}", rel_l2=e)
         assert torch.isfinite(got).all() and e < 6e-3, (name, e)
     assert rell2(att(q, k, v), ref(torch.zeros(1, device=DEV))) < 6e-3
+
+
+@pytest.mark.parametrize("D", [16, 32, 64, 128])
+@pytest.mark.parametrize("N", [64, 200, 1000])
+def test_masked_forward_op_random_bias(D, N):
+    """osuf_mqa_fwd_masked on its own: a dense random bf16 bias with a band of -inf key columns, every key tile (the second 32-key half of
+    a 64-key tile included -- a first version of the kernel got exactly that half wrong) and a ragged last tile."""
+    torch.manual_seed(D + N)
+    B, H = 2, 3
+    qkv = torch.randn(B, N, (H + 2) * D, device=DEV).to(torch.bfloat16)
+    x = qkv.float()
+    q = x[..., :H * D].view(B, N, H, D).permute(0, 2, 1, 3)
+    k, v = x[..., H * D:(H + 1) * D][:, None], x[..., (H + 1) * D:][:, None]
+    bias = torch.randn(B, H, N, N, device=DEV).to(torch.bfloat16)
+    bias[:, :, :, N // 2:N // 2 + 7] = float("-inf")
+    want = (((q @ k.transpose(-1, -2)) * D ** -0.5 + bias.float()).softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B, N, H * D)
+    got = ops.mqa_fwd_masked(qkv, bias, B, N, H, D, torch.bfloat16, D ** -0.5)
+    e = rell2(got, want)
+    report(f"attend_mask/op/D{D}/N{N}", rel_l2=e)
+    assert e < 4e-3
+    # a one-hot row of the bias selects exactly that key's value row
+    hot = torch.full((B, H, N, N), -1e4, device=DEV, dtype=torch.bfloat16)
+    key = min(N - 1, 33)
+    hot[..., key] = 0
+    got = ops.mqa_fwd_masked(qkv, hot, B, N, H, D, torch.float32, D ** -0.5)
+    assert torch.equal(got.view(B, N, H, D), v[:, 0, key][:, None, None, :].expand(B, N, H, D))
