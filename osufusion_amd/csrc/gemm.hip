@@ -624,7 +624,9 @@ __device__ __forceinline__ void gemm_big_epilogue(const GemmArgs& g, f32x16 (&ac
 
 // DBG (bottleneck triage builds, selected by OSUF_GEMM_DBG; results are garbage unless 0): 1 = no MFMA, 2 = no LDS fragment
 // reads, 3 = no global->LDS DMA, 4 = DMA only, 5 = DMA only from one hot 1-KiB region (memory-side vs LDS-side cost).
-template <typename T, int DBG = 0>
+// SPLIT (T = float, OSUF_DT_F32X3): fp32 stages (32 k per row), every fragment split in registers into bf16 hi + lo, three bf16
+// MFMAs per product (mfma_x3) -- two 16-deep k-steps per stage, 48 MFMAs per wave and stage against 32 of the bf16 kernel.
+template <typename T, int DBG = 0, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BK = Mma<T>::BK;
@@ -728,6 +730,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(GemmArgs g) {
     const bool more = DBG != 3 && step + 1 < nsteps;
     const char* sa = smem + buf * kBigStage;
     const char* sb = sa + kBig * 128;
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (more) { issue_part(buf ^ 1, 2 * ks); issue_part(buf ^ 1, 2 * ks + 1); }
+        bf16x8 ah[4], al[4], bh[2], bl[2];
+        auto frag = [&](const char* base, int row, bf16x8& hi, bf16x8& lo) {      // k = 16 ks + 8 lh + 0..7 of this lane's row
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(base + swz_off(row, 4 * ks + 2 * lh));
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(base + swz_off(row, 4 * ks + 2 * lh + 1));
+          const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+          split_bf16x8(x, hi, lo);
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) frag(sa, wr * 128 + i * 32 + lr, ah[i], al[i]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) frag(sb, wc * 64 + j * 32 + lr, bh[j], bl[j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) mfma_x3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       u32x4 fa[4], fb[2];
@@ -764,6 +787,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(GemmArgs g) {
             for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e], vb[e], acc[i][j], 0, 0, 0);
           }
         }
+    }
     }
     if (more) issue_done();
     __syncthreads();
@@ -1071,6 +1095,43 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs g) {
     }
 }
 
+// the 256 x 256 wgrad tile leaves either as a partial tile of its m-split (plain 128-B-segment stores, 5x the fp32-atomic rate; summed
+// by wgrad_reduce_kernel) or by fp32 atomics into dW
+__device__ __forceinline__ void tn_big_store(const WgradArgs& g, const f32x16 (&acc)[4][2], int split, int t, int n1_0, int n2_0, int wr, int wc,
+                                             int lr, int lh) {
+  if (g.ws) {
+    float* out = g.ws + ((long)split * g.taps + t) * g.N1 * g.N2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n2 = n2_0 + wc * 64 + j * 32 + lr;
+        if (n2 < g.N2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n1 = n1_0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (n1 < g.N1) out[(long)n1 * g.N2 + n2] = acc[i][j][r];
+          }
+        }
+      }
+    return;
+  }
+  float* dW = g.dW + (long)t * g.tapstride;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n2 = n2_0 + wc * 64 + j * 32 + lr;
+      if (n2 < g.N2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n1 = n1_0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (n1 < g.N1) atomic_add_f32(dW + (long)n1 * g.ldw + (long)n2 * g.es, acc[i][j][r]);
+        }
+      }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // 256x256 output tile wgrad (bf16): 8 waves (2x4), wave tile 128 (n1) x 64 (n2), 64 rows of m per step, LDS-DMA staging into a
 // 2 x 64 KiB ring.  Tiles are row-major as stored ([64 rows][256 cols] = 512 B per row); chunk ^= (row&3)<<2 keeps the
@@ -1211,38 +1272,107 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(WgradArgs g) {
 #undef TN_WAIT
 #undef TN_MFMA
 
-  if (g.ws) {
-    // partial tile of this m-split: plain 128-B-segment stores (5x the fp32-atomic rate), summed by wgrad_reduce_kernel
-    float* out = g.ws + ((long)split * g.taps + t) * g.N1 * g.N2;
+  tn_big_store(g, acc, split, t, n1_0, n2_0, wr, wc, lr, lh);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same 256 x 256 wgrad tile for OSUF_DT_F32X3: fp32 stages of 32 rows of m ([32][256] floats = 1 KiB per row and operand, one
+// LDS-DMA instruction per row), fragments gathered down the columns with ds_read_b32 (lanes = consecutive columns: conflict-free
+// without a swizzle), split into bf16 hi + lo in registers, three bf16 MFMAs per product (mfma_x3).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_tn_big_x3_kernel(WgradArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKM = 32, ROWB = 1024, TILEB = BKM * ROWB;      // 32 KiB per operand tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n2 = (g.N2 + kBig - 1) / kBig;
+  const int tiles_n1 = (g.N1 + kBig - 1) / kBig;
+  const int ntile = tiles_n1 * tiles_n2;                        // block -> (split, tile, tap) as in gemm_tn_big_kernel
+  const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;
+  const int unit = (qid / g.taps) * 8 + xcd;
+  const int t = qid % g.taps;
+  const int split = unit / ntile, tile = unit % ntile;
+  const int n1_0 = (tile / tiles_n2) * kBig, n2_0 = (tile % tiles_n2) * kBig;
+  const int m_begin = split * g.rows_per_split;
+  const int m_end = min(g.M, m_begin + g.rows_per_split);
+  if (m_begin >= m_end) return;
+  const float* dY = reinterpret_cast<const float*>(g.dY);
+  const float* X = reinterpret_cast<const float*>(g.X);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  // DMA role: instruction i of this wave fills tile row wave*4 + i, this lane its 16-B chunk `lane` (4 columns)
+  const int scol = lane * 4;
+  const bool y_ok = n1_0 + scol < g.N1, x_ok = n2_0 + scol < g.N2;
+  int sb_[4], sp_[4];
+  const char* py[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n2 = n2_0 + wc * 64 + j * 32 + lr;
-        if (n2 < g.N2) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int n1 = n1_0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (n1 < g.N1) out[(long)n1 * g.N2 + n2] = acc[i][j][r];
-          }
-        }
-      }
-    return;
+  for (int i = 0; i < 4; ++i) {
+    const int m = m_begin + wave * 4 + i;
+    sb_[i] = m / g.rm.Lout;
+    sp_[i] = m - sb_[i] * g.rm.Lout;
+    py[i] = reinterpret_cast<const char*>(dY + (long)m * g.ldy + n1_0 + scol);
   }
-  float* dW = g.dW + (long)t * g.tapstride;
+  const long ystep = (long)BKM * g.ldy * (long)sizeof(float);
+  auto issue = [&](int mb, int buf) {
+    char* sy = smem + buf * 2 * TILEB + wave * 4096;
+    char* sx = sy + TILEB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool in = mb + wave * 4 + i < m_end;
+      const char* qy = (in && y_ok) ? py[i] : zero;
+      const char* qx = zero;
+      if (in && x_ok) {
+        const int s2 = map_row(g.rm, sp_[i], t);
+        if (s2 >= 0) qx = reinterpret_cast<const char*>(X + (long)(sb_[i] * g.rm.Lin + s2) * g.ldx + n2_0 + scol);
+      }
+      __builtin_amdgcn_global_load_lds((gas_ptr)qy, (las_ptr)(sy + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gas_ptr)qx, (las_ptr)(sx + i * 1024), 16, 0, 0);
+      py[i] += ystep;
+      sp_[i] += BKM;
+      while (sp_[i] >= g.rm.Lout) { sp_[i] -= g.rm.Lout; ++sb_[i]; }
+    }
+  };
+
+  f32x16 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n2 = n2_0 + wc * 64 + j * 32 + lr;
-      if (n2 < g.N2) {
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n1 = n1_0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (n1 < g.N1) atomic_add_f32(dW + (long)n1 * g.ldw + (long)n2 * g.es, acc[i][j][r]);
-        }
-      }
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  issue(m_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  for (int mb = m_begin; mb < m_end; mb += BKM, buf ^= 1) {
+    if (mb + BKM < m_end) issue(mb + BKM, buf ^ 1);
+    const char* sy = smem + buf * 2 * TILEB;
+    const char* sx = sy + TILEB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 ah[4], al[4], bh[2], bl[2];
+      auto frag = [&](const char* base, int col, bf16x8& hi, bf16x8& lo) {      // rows 16 kk + 8 lh + 0..7 of column `col`
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = *reinterpret_cast<const float*>(base + (16 * kk + 8 * lh + e) * ROWB + col * 4);
+        split_bf16x8(x, hi, lo);
+      };
+#pragma unroll
+      for (int i = 0; i < 4; ++i) frag(sy, wr * 128 + i * 32 + lr, ah[i], al[i]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) frag(sx, wc * 64 + j * 32 + lr, bh[j], bl[j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mfma_x3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  tn_big_store(g, acc, split, t, n1_0, n2_0, wr, wc, lr, lh);
 }
 
 // deterministic second stage of the split wgrad: dW (+)= sum_s ws[s][t][i], i = n1*N2 + n2.
@@ -1566,7 +1696,7 @@ static int gemm_nt_launch(int dtype, const void* A, long lda, const void* W, lon
   const char* bigenv = getenv("OSUF_GEMM_BIG_MIN_TILES");
   const long min_tiles = bigenv ? atol(bigenv) : 192;
   const long big_tiles = (long)((M + kBig - 1) / kBig) * ((N + kBig - 1) / kBig);
-  const bool use_big = !regstage && dtype == OSUF_DT_BF16 && min_tiles > 0 && big_tiles >= min_tiles && (N >= 192 || bigenv) && N % 8 == 0 &&
+  const bool use_big = !regstage && (dtype == OSUF_DT_BF16 || dtype == OSUF_DT_F32X3) && min_tiles > 0 && big_tiles >= min_tiles && (N >= 192 || bigenv) && N % 8 == 0 &&
                        ldc % 8 == 0 && (!C2 || ldc2 % 8 == 0) && (!R || ldr % 8 == 0) && (!U || ldu % 8 == 0) &&
                        (!bias || (reinterpret_cast<uintptr_t>(bias) & 31) == 0) && (!rscale || (reinterpret_cast<uintptr_t>(rscale) & 31) == 0);
   if (use_big) {
@@ -1574,6 +1704,7 @@ static int gemm_nt_launch(int dtype, const void* A, long lda, const void* W, lon
     static bool big_attr = false;
     if (!big_attr) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
+      (void)hipFuncSetAttribute((const void*)(gemm_nt_big_kernel<float, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<bf16_t, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
@@ -1584,7 +1715,8 @@ static int gemm_nt_launch(int dtype, const void* A, long lda, const void* W, lon
     const long tm = (M + kBig - 1) / kBig, tn = (N + kBig - 1) / kBig;
     const int dbg = getenv("OSUF_GEMM_DBG") ? atoi(getenv("OSUF_GEMM_DBG")) : 0;
     const dim3 grid_big((int)(((tm + 7) / 8) * 8 * tn));
-    if (dbg == 1) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 1>), grid_big, dim3(512), lds_big, stream, g);
+    if (dtype == OSUF_DT_F32X3) hipLaunchKernelGGL((gemm_nt_big_kernel<float, 0, true>), grid_big, dim3(512), lds_big, stream, g);
+    else if (dbg == 1) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 1>), grid_big, dim3(512), lds_big, stream, g);
     else if (dbg == 2) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 2>), grid_big, dim3(512), lds_big, stream, g);
     else if (dbg == 3) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 3>), grid_big, dim3(512), lds_big, stream, g);
     else if (dbg == 4) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 4>), grid_big, dim3(512), lds_big, stream, g);
@@ -1606,7 +1738,7 @@ static bool tn_big_plan(int dtype, int M, int N1, int N2, int taps, int* rows_ou
   const char* bigenv = getenv("OSUF_GEMM_BIG_MIN_TILES");
   const bool forced = bigenv && atol(bigenv) == 1, off = bigenv && atol(bigenv) <= 0;
   const int lo = getenv("OSUF_TN_BIG_MIN_N") ? atoi(getenv("OSUF_TN_BIG_MIN_N")) : 64;
-  if (dtype != OSUF_DT_BF16 || off || !(forced || (N1 >= lo && N2 >= lo && (N1 >= 192 || N2 >= 192)))) return false;
+  if ((dtype != OSUF_DT_BF16 && dtype != OSUF_DT_F32X3) || off || !(forced || (N1 >= lo && N2 >= lo && (N1 >= 192 || N2 >= 192)))) return false;
   const int btiles = ((N1 + kBig - 1) / kBig) * ((N2 + kBig - 1) / kBig);
   int sp = (256 + btiles * taps / 2) / (btiles * taps);        // one workgroup per CU: about one round of the 256 CUs
   if (sp < 1) sp = 1;
@@ -1679,8 +1811,13 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
       const int btiles = ((N1 + kBig - 1) / kBig) * ((N2 + kBig - 1) / kBig);
       const int lds_big = 2 * 65536;
       static bool attr = false;
-      if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big); attr = true; }
-      hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(((sp * btiles + 7) / 8) * 8 * taps), dim3(512), lds_big, stream, gb);
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_big_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
+        attr = true;
+      }
+      if (dtype == OSUF_DT_F32X3) hipLaunchKernelGGL(gemm_tn_big_x3_kernel, dim3(((sp * btiles + 7) / 8) * 8 * taps), dim3(512), lds_big, stream, gb);
+      else hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(((sp * btiles + 7) / 8) * 8 * taps), dim3(512), lds_big, stream, gb);
       if (gb.ws) {
         const long n12 = (long)N1 * N2;
         const long groups = out_layout == 1 ? n12 / 4 : n / 4;            // float4 output groups (x taps partial reads each in layout 1)

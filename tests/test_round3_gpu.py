@@ -276,11 +276,14 @@ def test_attention_module_head_dims_vs_oracle(D, heads, kv_heads):
         assert rell2(q.grad, p[f"a.{k}"].grad) < 3e-2, k
 
 
+@pytest.mark.parametrize("big", [False, True])
 @pytest.mark.parametrize("M,N,K,taps", [(1024, 256, 256, 3), (520, 96, 40, 1), (2048, 768, 512, 1)])
-def test_f32x3_gemms_keep_seventeen_bits(M, N, K, taps):
+def test_f32x3_gemms_keep_seventeen_bits(monkeypatch, M, N, K, taps, big):
     """OSUF_DT_F32X3 (fp32 storage, three bf16 MFMAs on split operands) for the conv / linear GEMMs and their weight gradients against an
     fp64 product: an order of magnitude and a half inside north_star's 1e-3, two orders better than bf16 operands (residual.py:70,115,
-    unet.py:118-123,149-156 in an fp32 run)."""
+    unet.py:118-123,149-156 in an fp32 run).  big: the 256x256 LDS-DMA kernels' x3 paths forced onto these small ragged shapes."""
+    if big:
+        monkeypatch.setenv("OSUF_GEMM_BIG_MIN_TILES", "1")
     torch.manual_seed(1)
     L = M // 2
     a = torch.randn(M, K, device=DEV)
@@ -315,7 +318,7 @@ def test_f32x3_gemms_keep_seventeen_bits(M, N, K, taps):
     e_w = rell2(errs["x3"][1], gw_ref)
     bf = ops.gemm_nt(a.to(torch.bfloat16), w.to(torch.bfloat16), None, **kw)
     e_bf = rell2(bf.float(), want)
-    report(f"f32x3/M{M}N{N}K{K}t{taps}", exact=errs["exact"][0], x3=errs["x3"][0], bf16=e_bf, wgrad_x3_vs_exact=e_w)
+    report(f"f32x3/M{M}N{N}K{K}t{taps}{'/big' if big else ''}", exact=errs["exact"][0], x3=errs["x3"][0], bf16=e_bf, wgrad_x3_vs_exact=e_w)
     assert errs["exact"][0] < 2e-6
     assert errs["x3"][0] < 3e-5 and e_w < 3e-5, (errs["x3"][0], e_w)
     assert e_bf > 30 * errs["x3"][0]
