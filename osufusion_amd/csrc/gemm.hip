@@ -1097,8 +1097,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(WgradArgs g) {
 
 // the 256 x 256 wgrad tile leaves either as a partial tile of its m-split (plain 128-B-segment stores, 5x the fp32-atomic rate; summed
 // by wgrad_reduce_kernel) or by fp32 atomics into dW
+// (IL: the x3 kernel's n1 mapping -- MFMA row rho of tile i is column 4 rho + i of the wave's 128, see its fragment reads)
+template <bool IL = false>
 __device__ __forceinline__ void tn_big_store(const WgradArgs& g, const f32x16 (&acc)[4][2], int split, int t, int n1_0, int n2_0, int wr, int wc,
                                              int lr, int lh) {
+  auto n1_of = [&](int i, int r) {
+    const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    return n1_0 + wr * 128 + (IL ? 4 * rho + i : i * 32 + rho);
+  };
   if (g.ws) {
     float* out = g.ws + ((long)split * g.taps + t) * g.N1 * g.N2;
 #pragma unroll
@@ -1109,7 +1115,7 @@ __device__ __forceinline__ void tn_big_store(const WgradArgs& g, const f32x16 (&
         if (n2 < g.N2) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int n1 = n1_0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int n1 = n1_of(i, r);
             if (n1 < g.N1) out[(long)n1 * g.N2 + n2] = acc[i][j][r];
           }
         }
@@ -1125,7 +1131,7 @@ __device__ __forceinline__ void tn_big_store(const WgradArgs& g, const f32x16 (&
       if (n2 < g.N2) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int n1 = n1_0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int n1 = n1_of(i, r);
           if (n1 < g.N1) atomic_add_f32(dW + (long)n1 * g.ldw + (long)n2 * g.es, acc[i][j][r]);
         }
       }
@@ -1354,16 +1360,26 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_x3_kernel(WgradArgs g) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 ah[4], al[4], bh[2], bl[2];
-      auto frag = [&](const char* base, int col, bf16x8& hi, bf16x8& lo) {      // rows 16 kk + 8 lh + 0..7 of column `col`
+      // dY side: one ds_read_b128 per row of m hands this lane columns 4 lr .. 4 lr + 3 of the wave's 128 = its k-element for all
+      // four M-tiles (tile i owns the columns congruent i mod 4; tn_big_store<true> undoes the interleave) -- 8 wide reads instead of
+      // 32 ds_read_b32, which had the LDS array as busy as the matrix cores.  X side: lanes = consecutive columns (coalesced stores).
+      {
+        f32x4 y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = *reinterpret_cast<const f32x4*>(sy + (16 * kk + 8 * lh + e) * ROWB + (wr * 128 + 4 * lr) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x[8] = {y[0][i], y[1][i], y[2][i], y[3][i], y[4][i], y[5][i], y[6][i], y[7][i]};
+          split_bf16x8(x, ah[i], al[i]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
         float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = *reinterpret_cast<const float*>(base + (16 * kk + 8 * lh + e) * ROWB + col * 4);
-        split_bf16x8(x, hi, lo);
-      };
-#pragma unroll
-      for (int i = 0; i < 4; ++i) frag(sy, wr * 128 + i * 32 + lr, ah[i], al[i]);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) frag(sx, wc * 64 + j * 32 + lr, bh[j], bl[j]);
+        for (int e = 0; e < 8; ++e) x[e] = *reinterpret_cast<const float*>(sx + (16 * kk + 8 * lh + e) * ROWB + (wc * 64 + j * 32 + lr) * 4);
+        split_bf16x8(x, bh[j], bl[j]);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1372,7 +1388,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_x3_kernel(WgradArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  tn_big_store(g, acc, split, t, n1_0, n2_0, wr, wc, lr, lh);
+  tn_big_store<true>(g, acc, split, t, n1_0, n2_0, wr, wc, lr, lh);
 }
 
 // deterministic second stage of the split wgrad: dW (+)= sum_s ws[s][t][i], i = n1*N2 + n2.
