@@ -797,6 +797,123 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k = 3 "same" convolutions (residual.py:70 and their input gradients; mode 0, stride 1, pad 1, L % 256 == 0, K % 64 == 0) on the same
+// 256 x 256 tile with the activation panel SHARED by the three taps.  The plain kernel streams an A tile per (tap, K-step) although
+// tap t's rows are the same rows shifted by t - 1; its loop is bound by the L2 -> LDS feed (touching the next A lines
+// early made it slower, more bytes through the same pipe), so bytes per MFMA are what count.  Here a K-step loads ONE panel of 258 rows
+// (tile rows -1 .. 256; the two halo rows come from the zero page at a sample edge -- a tile never straddles samples) and three B
+// tiles: 129 KiB per three steps instead of 192.  K-steps are the outer loop, taps the inner one (fp32 summation order differs from
+// the plain kernel's tap-major order).  LDS: 2 panels x 264 rows x 128 B + 2 x 32 KiB of B = 130 KiB; epilogue shared.
+// ---------------------------------------------------------------------------------------------------------
+static constexpr int kPanelRows = 264;                       // 33 DMA groups of 8 rows
+static constexpr int kPanelBytes = kPanelRows * 128;
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_big_halo3_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (g.N + kBig - 1) / kBig;
+  const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;       // tile order as in gemm_nt_big_kernel
+  const int mt = (qid / tiles_n) * 8 + xcd;
+  const int m0 = mt * kBig, n0 = (qid % tiles_n) * kBig;
+  if (m0 >= g.M) return;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  const int L = g.rm.Lout;
+  const int pos0 = m0 % L;                                   // position of the tile's first row inside its sample
+  const int ksteps = g.K / 64;
+
+  // A panel: group gi (8 rows) of wave w is 4 w + i, i < 4; wave 0 also loads group 32 (rows 256 .. 263, of which 256 and 257 are read)
+  const char* pa[5];
+  int ia[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int r = ((i < 4 ? wave * 4 + i : 32) * 8) + (lane >> 3);       // panel row; activation row m0 - 1 + r
+    const int pos = pos0 - 1 + r;
+    const bool ok = r < 258 && pos >= 0 && pos < L;
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    pa[i] = ok ? reinterpret_cast<const char*>(A + (long)(m0 - 1 + r) * g.lda + c * 8) : zero;
+    ia[i] = ok ? 128 : 0;
+  }
+  // B tiles: this lane's row of W for DMA instruction i, tap 0, K-step 0
+  const char* pb[4];
+  bool b_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    b_ok[i] = n0 + row < g.N;
+    pb[i] = b_ok[i] ? reinterpret_cast<const char*>(W + (long)(n0 + row) * g.ldw + c * 8) : zero;
+  }
+  const long tapb = g.tapstride * (long)sizeof(T);
+  char* panels = smem;
+  char* bring = smem + 2 * kPanelBytes;
+  auto issue_a = [&](int panel, int i) {                      // group i of this wave into panel `panel`; advances to the next K-step
+    const int gi = i < 4 ? wave * 4 + i : 32;
+    __builtin_amdgcn_global_load_lds((gas_ptr)pa[i], (las_ptr)(panels + panel * kPanelBytes + gi * 1024), 16, 0, 0);
+    pa[i] += ia[i];
+  };
+  auto issue_b = [&](int slot, int i, int t, int kb) {
+    const char* q = b_ok[i] ? pb[i] + (long)t * tapb + (long)kb * 128 : zero;
+    __builtin_amdgcn_global_load_lds((gas_ptr)q, (las_ptr)(bring + slot * 32768 + (wave * 4 + i) * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue_a(0, i);
+  if (wave == 0) issue_a(0, 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue_b(0, i, 0, 0);
+  __syncthreads();
+
+  for (int kb = 0; kb < ksteps; ++kb) {
+    const char* pan = panels + (kb & 1) * kPanelBytes;
+    const bool more_k = kb + 1 < ksteps;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int slot = (kb + t) & 1;                          // (3 kb + t) & 1
+      const char* sb = bring + slot * 32768;
+      const bool more = t < 2 || more_k;
+      const int tn = t < 2 ? t + 1 : 0, kn = t < 2 ? kb : kb + 1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (more) issue_b(slot ^ 1, ks, tn, kn);
+        if (more_k) {                                        // next panel: two groups beside tap 0, one beside taps 1 and 2
+          if (t == 0 && ks == 1) issue_a((kb + 1) & 1, 0);
+          if (t == 0 && ks == 3) issue_a((kb + 1) & 1, 1);
+          if (t == 1 && ks == 1) issue_a((kb + 1) & 1, 2);
+          if (t == 2 && ks == 1) issue_a((kb + 1) & 1, 3);
+          if (t == 2 && ks == 3 && wave == 0) issue_a((kb + 1) & 1, 4);
+        }
+        u32x4 fa[4], fb[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(pan + swz_off(wr * 128 + i * 32 + lr + t, 2 * ks + lh));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const u32x4*>(sb + swz_off(wc * 64 + j * 32 + lr, 2 * ks + lh));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  gemm_big_epilogue<T>(g, acc, smem, m0, n0, tid, lane, wave, wr, wc);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Skinny-N variant (N <= 32: the rank-r LoRA products u = A(x) and du = dy (s g B), functional.adapter_grads): a 256 x 32 tile per
 // workgroup -- 8 waves x one 32x32 MFMA tile -- so the DMA traffic is the A panel only (the 128 / 256-wide tiles spend 4-8x the
 // MFMAs and B-side DMA slots on zero columns).  Same loader (per-tap row maps, incremental pointers), 2 x 36 KiB ring -> two
@@ -1731,7 +1848,13 @@ static int gemm_nt_launch(int dtype, const void* A, long lda, const void* W, lon
     const long tm = (M + kBig - 1) / kBig, tn = (N + kBig - 1) / kBig;
     const int dbg = getenv("OSUF_GEMM_DBG") ? atoi(getenv("OSUF_GEMM_DBG")) : 0;
     const dim3 grid_big((int)(((tm + 7) / 8) * 8 * tn));
-    if (dtype == OSUF_DT_F32X3) hipLaunchKernelGGL((gemm_nt_big_kernel<float, 0, true>), grid_big, dim3(512), lds_big, stream, g);
+    const bool halo3 = dtype == OSUF_DT_BF16 && taps == 3 && mode == 0 && stride == 1 && pad == 1 && Lin == Lout && Lout % kBig == 0 && K % 64 == 0 &&
+                       dbg == 0 && getenv("OSUF_GEMM_NOHALO") == nullptr;
+    if (halo3) {
+      static bool halo_attr = ((void)hipFuncSetAttribute((const void*)gemm_nt_big_halo3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big), true);
+      (void)halo_attr;
+      hipLaunchKernelGGL(gemm_nt_big_halo3_kernel, grid_big, dim3(512), lds_big, stream, g);
+    } else if (dtype == OSUF_DT_F32X3) hipLaunchKernelGGL((gemm_nt_big_kernel<float, 0, true>), grid_big, dim3(512), lds_big, stream, g);
     else if (dbg == 1) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 1>), grid_big, dim3(512), lds_big, stream, g);
     else if (dbg == 2) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 2>), grid_big, dim3(512), lds_big, stream, g);
     else if (dbg == 3) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 3>), grid_big, dim3(512), lds_big, stream, g);

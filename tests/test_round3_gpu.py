@@ -411,3 +411,38 @@ def test_masked_forward_op_random_bias(D, N):
     hot[..., key] = 0
     got = ops.mqa_fwd_masked(qkv, hot, B, N, H, D, torch.float32, D ** -0.5)
     assert torch.equal(got.view(B, N, H, D), v[:, 0, key][:, None, None, :].expand(B, N, H, D))
+
+
+@pytest.mark.parametrize("Cin,Cout,L,Bq", [(128, 328, 512, 3), (64, 256, 256, 4), (192, 72, 768, 2)])
+def test_halo_shared_k3_conv_kernel(monkeypatch, Cin, Cout, L, Bq):
+    """gemm_nt_big_halo3_kernel (k = 3 'same' convs and their input gradients with L % 256 == 0: one activation panel per K-step shared by
+    the three taps) forced onto small shapes: against the plain 256x256 kernel (same products, K-step-major instead of tap-major fp32
+    sums) and against conv1d on the bf16-rounded operands -- sample edges (halo rows from the zero page), N tail, every epilogue
+    option, residual.py:70."""
+    import torch.nn.functional as F
+    from tests.test_hip_parity import relmax
+    torch.manual_seed(Cin + L)
+    monkeypatch.setenv("OSUF_GEMM_BIG_MIN_TILES", "1")
+    x = torch.randn(Bq, L, Cin, device=DEV).to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, 3, device=DEV) / (Cin * 3) ** 0.5
+    bias = torch.randn(Cout, device=DEV)
+    res = torch.randn(Bq, L, Cout, device=DEV).to(torch.bfloat16)
+    rscale = torch.rand(Bq, Cout, device=DEV)
+    outs = []
+    for nohalo in (True, False):
+        if nohalo:
+            monkeypatch.setenv("OSUF_GEMM_NOHALO", "1")
+        else:
+            monkeypatch.delenv("OSUF_GEMM_NOHALO")
+        stats = torch.zeros(Bq, 2, dtype=torch.float64, device=DEV)
+        y, pre = Fn.conv_forward(x, w, bias, Fn.PackCache(), "same", None, act=1, residual=res, rscale=rscale, stats=stats, want_pre=True)
+        dx = Fn.conv_dgrad(y, w, Fn.PackCache(), "same", L, residual=x)
+        outs.append((y.float(), pre.float(), stats.clone(), dx.float()))
+    (y0, p0, s0, d0), (y1, p1, s1, d1) = outs
+    for u, v in ((p0, p1), (y0, y1), (d0, d1)):       # different fp32 summation order: a bf16 ulp on a few elements at most
+        assert torch.allclose(u, v, rtol=2.0 ** -7, atol=2e-3) and (u != v).float().mean().item() < 2e-2
+    assert torch.allclose(s0, s1, rtol=1e-5)
+    ref = F.conv1d(x.float().permute(0, 2, 1), w.to(torch.bfloat16).float(), bias, padding=1)
+    assert relmax(p1.permute(0, 2, 1), ref) < 1e-2
+    # a sample's first and last rows see zeros, not the neighbouring sample's rows
+    assert relmax(p1[:, [0, L - 1]].permute(0, 2, 1), ref[:, :, [0, L - 1]]) < 1e-2

@@ -11,7 +11,8 @@ def timeit(fn, iters=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
 M = 131072
-for N, K in ((1024, 1024), (1024, 256)):
+shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(1024, 1024), (1024, 256)]      # N,K pairs
+for N, K in shapes:
     x = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(1, N, K, device="cuda") * 0.05).bfloat16()
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     t = timeit(lambda: ops.gemm_nt(x, w, None, out=out))
