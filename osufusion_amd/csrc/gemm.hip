@@ -1508,6 +1508,148 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_x3_kernel(WgradArgs g) {
   tn_big_store<true>(g, acc, split, t, n1_0, n2_0, wr, wc, lr, lh);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient of the k = 3 'same' convolutions with the three taps in ONE workgroup (mode 0, stride 1, pad 1, L % 128 == 0): a
+// 128 (n1) x 128 (n2) tile per tap, 8 waves (2 x 4), wave tile 64 x 32 x 3 taps = 96 accumulator registers.  A stage is 128 rows of m:
+// the dY tile (32 KiB) and ONE X panel of 130 rows (rows -1 .. 128; the two halo rows come from the zero page at a sample edge, a stage
+// never straddles samples) that serves all three taps -- 65 KiB through the L2 -> LDS feed per 6.3 M MACs, two thirds of the bytes per MAC
+// of gemm_tn_big_kernel's one-workgroup-per-tap tiles (the loop is bound by that feed: DESIGN.md section 4).  Tiles are row-major as
+// stored (256 B per row), byte-in-row ^= (row & 3) << 6 keeps the ds_read_b64_tr_b16 fragment reads conflict-free; transposed reads by
+// inline asm, software-pipelined one k-step ahead, as in gemm_tn_big_kernel.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_tn_taps3_kernel(WgradArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKM = 128, ROWB = 256, YB = BKM * ROWB, XROWS = 132, STAGE = YB + XROWS * ROWB;      // 32 KiB + 33 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n2 = (g.N2 + 127) / 128, tiles_n1 = (g.N1 + 127) / 128;
+  const int ntile = tiles_n1 * tiles_n2;
+  const int split = blockIdx.x / ntile, tile = blockIdx.x % ntile;
+  const int n1_0 = (tile / tiles_n2) * 128, n2_0 = (tile % tiles_n2) * 128;
+  const int m_begin = split * g.rows_per_split;
+  const int m_end = min(g.M, m_begin + g.rows_per_split);
+  if (m_begin >= m_end) return;
+  const bf16_t* dY = reinterpret_cast<const bf16_t*>(g.dY);
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(g.X);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  const int L = g.rm.Lout;
+
+  // DMA roles: an instruction moves 4 rows x 256 B; instruction i < 4 of wave w is tile / panel rows (4 w + i) * 4 + (lane >> 4);
+  // wave 0's fifth X instruction is panel rows 128 .. 131.  LDS position lane & 15 of a row holds logical chunk (lane & 15) ^ ((row & 3) << 2).
+  int yrow[4], prow[5], ycol[4], pcol[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int r = ((i < 4 ? wave * 4 + i : 32) * 4) + (lane >> 4);
+    const int col = ((lane & 15) ^ ((r & 3) << 2)) * 8;
+    prow[i] = r; pcol[i] = col;
+    if (i < 4) { yrow[i] = r; ycol[i] = col; }
+  }
+  int pos = m_begin % L;                                      // position of the stage's first row inside its sample
+  auto issue = [&](int mb, int buf) {
+    char* sy = smem + buf * STAGE;
+    char* sx = sy + YB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mb + yrow[i];
+      const char* qy = (m < m_end && n1_0 + ycol[i] < g.N1) ? reinterpret_cast<const char*>(dY + (long)m * g.ldy + n1_0 + ycol[i]) : zero;
+      __builtin_amdgcn_global_load_lds((gas_ptr)qy, (las_ptr)(sy + (wave * 4 + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      if (i == 4 && wave != 0) break;
+      const int pr = prow[i];                                 // panel row pr = X row mb - 1 + pr
+      const int q = pos - 1 + pr;
+      const bool ok = pr < 130 && q >= 0 && q < L && mb - 1 + pr < g.M && n2_0 + pcol[i] < g.N2;
+      const char* qx = ok ? reinterpret_cast<const char*>(X + (long)(mb - 1 + pr) * g.ldx + n2_0 + pcol[i]) : zero;
+      __builtin_amdgcn_global_load_lds((gas_ptr)qx, (las_ptr)(sx + (i < 4 ? wave * 4 + i : 32) * 1024), 16, 0, 0);
+    }
+    pos += BKM;
+    if (pos >= L) pos -= L;
+  };
+
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  const int ip = lane & 15, cb = ((lane >> 4) & 1) * 16, tq = ip >> 2, tp = ip & 3;
+  uint32_t offA[2], offB[3];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) offA[i] = (8 * lh + tq) * ROWB + (((wr * 64 + i * 32 + cb + 4 * tp) * 2) ^ (tq << 6));
+#pragma unroll
+  for (int t = 0; t < 3; ++t) offB[t] = YB + (8 * lh + tq + t) * ROWB + (((wc * 32 + cb + 4 * tp) * 2) ^ (((tq + t) & 3) << 6));
+
+  typedef u32x2 frag_half;
+  frag_half fa[2][2][2], fb[2][3][2];                           // [pipeline slot][tile / tap][lo/hi]
+#define T3_READS(slot, ks, base)                                                                                   \
+  OSUF_TR_READ(fa[slot][0][0], base + offA[0], (ks) * 16 * 256); OSUF_TR_READ(fa[slot][0][1], base + offA[0], ((ks) * 16 + 4) * 256); \
+  OSUF_TR_READ(fa[slot][1][0], base + offA[1], (ks) * 16 * 256); OSUF_TR_READ(fa[slot][1][1], base + offA[1], ((ks) * 16 + 4) * 256); \
+  OSUF_TR_READ(fb[slot][0][0], base + offB[0], (ks) * 16 * 256); OSUF_TR_READ(fb[slot][0][1], base + offB[0], ((ks) * 16 + 4) * 256); \
+  OSUF_TR_READ(fb[slot][1][0], base + offB[1], (ks) * 16 * 256); OSUF_TR_READ(fb[slot][1][1], base + offB[1], ((ks) * 16 + 4) * 256); \
+  OSUF_TR_READ(fb[slot][2][0], base + offB[2], (ks) * 16 * 256); OSUF_TR_READ(fb[slot][2][1], base + offB[2], ((ks) * 16 + 4) * 256);
+#define T3_WAIT(slot, n)                                                                                          \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                                        \
+               : "+v"(fa[slot][0][0]), "+v"(fa[slot][0][1]), "+v"(fa[slot][1][0]), "+v"(fa[slot][1][1]), "+v"(fb[slot][0][0]),  \
+                 "+v"(fb[slot][0][1]), "+v"(fb[slot][1][0]), "+v"(fb[slot][1][1]), "+v"(fb[slot][2][0]), "+v"(fb[slot][2][1]));  \
+  __builtin_amdgcn_sched_barrier(0);
+#define T3_MFMA(slot)                                                                                             \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int t = 0; t < 3; ++t) {                   \
+    u32x4 va = {fa[slot][i][0][0], fa[slot][i][0][1], fa[slot][i][1][0], fa[slot][i][1][1]};                       \
+    u32x4 vb = {fb[slot][t][0][0], fb[slot][t][0][1], fb[slot][t][1][0], fb[slot][t][1][1]};                       \
+    acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, vb), acc[i][t], 0, 0, 0); \
+  }
+
+  issue(m_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  for (int mb = m_begin; mb < m_end; mb += BKM, buf ^= 1) {
+    if (mb + BKM < m_end) issue(mb + BKM, buf ^ 1);
+    const uint32_t base = lds0 + buf * STAGE;
+    T3_READS(0, 0, base)
+    T3_READS(1, 1, base)
+    T3_WAIT(0, 10)  T3_MFMA(0)  T3_READS(0, 2, base)
+    T3_WAIT(1, 10)  T3_MFMA(1)  T3_READS(1, 3, base)
+    T3_WAIT(0, 10)  T3_MFMA(0)  T3_READS(0, 4, base)
+    T3_WAIT(1, 10)  T3_MFMA(1)  T3_READS(1, 5, base)
+    T3_WAIT(0, 10)  T3_MFMA(0)  T3_READS(0, 6, base)
+    T3_WAIT(1, 10)  T3_MFMA(1)  T3_READS(1, 7, base)
+    T3_WAIT(0, 10)  T3_MFMA(0)
+    T3_WAIT(1, 0)   T3_MFMA(1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#undef T3_READS
+#undef T3_WAIT
+#undef T3_MFMA
+
+  // partial tiles of this m-split ([split][tap][N1][N2], plain stores; summed by the wgrad_reduce kernels) or fp32 atomics into dW
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float* out = g.ws ? g.ws + ((long)split * 3 + t) * g.N1 * g.N2 : g.dW + (long)t * g.tapstride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int n2 = n2_0 + wc * 32 + lr;
+      if (n2 < g.N2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n1 = n1_0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (n1 < g.N1) {
+            if (g.ws) out[(long)n1 * g.N2 + n2] = acc[i][t][r];
+            else atomic_add_f32(out + (long)n1 * g.ldw + (long)n2 * g.es, acc[i][t][r]);
+          }
+        }
+      }
+    }
+  }
+}
+
 // deterministic second stage of the split wgrad: dW (+)= sum_s ws[s][t][i], i = n1*N2 + n2.
 // LAYOUT 0: dW[t][i] (the kernel's own order)   LAYOUT 1: dW[i][t] = torch's (Cout, Cin, k) conv weight layout -- the permute
 // is free here: a thread owns one i and writes its `taps` values contiguously.
@@ -1886,8 +2028,8 @@ static bool tn_big_plan(int dtype, int M, int N1, int N2, int taps, int* rows_ou
   while (sp > 1 && ((sp * btiles + 7) / 8) * 8 * taps > 256) --sp;
   int rows = (M + sp - 1) / sp;
   rows = ((rows + 63) / 64) * 64;
-  *rows_out = rows;
-  *splits_out = (M + rows - 1) / rows;
+  if (rows_out) *rows_out = rows;
+  if (splits_out) *splits_out = (M + rows - 1) / rows;
   return true;
 }
 
@@ -1933,6 +2075,42 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
     static bool sk_attr = ((void)hipFuncSetAttribute((const void*)gemm_tn_skinny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_sk), true);
     (void)sk_attr;
     hipLaunchKernelGGL(gemm_tn_skinny_kernel, dim3(tiles_n1 * taps * sp), dim3(512), lds_sk, stream, gs);
+    return osuf_launch_status();
+  }
+  if (splits <= 0 && dtype == OSUF_DT_BF16 && taps == 3 && mode == 0 && stride == 1 && pad == 1 && Lin == Lout && Lout % 128 == 0 && N1 >= 64 &&
+      N2 >= 64 && tn_big_plan(dtype, M, N1, N2, taps, nullptr, nullptr) && getenv("OSUF_GEMM_NOHALO") == nullptr) {
+    // the three taps in one workgroup (gemm_tn_taps3_kernel): 128 x 128 tiles, about one round of the 256 CUs
+    const int btiles = ((N1 + 127) / 128) * ((N2 + 127) / 128);
+    int sp = 256 / btiles;
+    if (sp < 1) sp = 1;
+    int rows = (M + sp - 1) / sp;
+    rows = ((rows + 127) / 128) * 128;
+    sp = (M + rows - 1) / rows;
+    WgradArgs gb;
+    gb.dY = dY; gb.X = X; gb.dW = dW; gb.ldy = ldy; gb.ldx = ldx; gb.ldw = ldw; gb.tapstride = tapstride;
+    gb.M = M; gb.N1 = N1; gb.N2 = N2; gb.taps = taps; gb.rm = RowMap{Lin, Lout, stride, pad, mode};
+    gb.rows_per_split = rows;
+    const long n = (long)taps * N1 * N2;
+    const bool dense = (out_layout == 1 && ((long)N1 * N2) % 4 == 0) || (out_layout == 0 && ldw == N2 && tapstride == (long)N1 * N2 && n % 4 == 0 && aligned16(dW));
+    gb.ws = (workspace && dense && aligned16(workspace) && workspace_bytes >= (long)sp * n * (long)sizeof(float)) ? workspace : nullptr;
+    gb.es = es;
+    if (!gb.ws && !accumulate) (void)hipMemsetAsync(dW, 0, (size_t)n * sizeof(float), stream);    // atomic path needs zeros
+    const int lds_t3 = 2 * (128 * 256 + 132 * 256);
+    static bool t3_attr = ((void)hipFuncSetAttribute((const void*)gemm_tn_taps3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_t3), true);
+    (void)t3_attr;
+    hipLaunchKernelGGL(gemm_tn_taps3_kernel, dim3(sp * btiles), dim3(512), lds_t3, stream, gb);
+    if (gb.ws) {
+      const long n12 = (long)N1 * N2;
+      const long groups = out_layout == 1 ? n12 / 4 : n / 4;
+      long blocks = (groups + 255) / 256;
+      if (blocks > 2048) blocks = 2048;
+      if (sp >= 8 && blocks < 512) {
+        const long b4 = (groups + 63) / 64;
+        if (out_layout == 1) hipLaunchKernelGGL(wgrad_reduce4_kernel<1>, dim3((int)b4), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
+        else hipLaunchKernelGGL(wgrad_reduce4_kernel<0>, dim3((int)b4), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
+      } else if (out_layout == 1) hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((int)blocks), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
+      else hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3((int)blocks), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
+    }
     return osuf_launch_status();
   }
   {

@@ -437,8 +437,13 @@ def test_halo_shared_k3_conv_kernel(monkeypatch, Cin, Cout, L, Bq):
         stats = torch.zeros(Bq, 2, dtype=torch.float64, device=DEV)
         y, pre = Fn.conv_forward(x, w, bias, Fn.PackCache(), "same", None, act=1, residual=res, rscale=rscale, stats=stats, want_pre=True)
         dx = Fn.conv_dgrad(y, w, Fn.PackCache(), "same", L, residual=x)
-        outs.append((y.float(), pre.float(), stats.clone(), dx.float()))
-    (y0, p0, s0, d0), (y1, p1, s1, d1) = outs
+        dw = Fn.conv_wgrad(res, x, w, "same")                  # gemm_tn_taps3_kernel (three taps per workgroup, one X panel) when not "nohalo"
+        outs.append((y.float(), pre.float(), stats.clone(), dx.float(), dw.float()))
+    (y0, p0, s0, d0, w0), (y1, p1, s1, d1, w1) = outs
+    assert relmax(w1, w0) < 1e-5                               # same bf16 products, different fp32 summation order
+    xs = F.pad(x.float(), (0, 0, 1, 1))                        # zero rows at the sample edges
+    want = torch.stack([torch.einsum("blo,bli->oi", res.float(), xs[:, t:t + L]) for t in range(3)], dim=-1)
+    assert relmax(w1.reshape(want.shape), want) < 1e-4
     for u, v in ((p0, p1), (y0, y1), (d0, d1)):       # different fp32 summation order: a bf16 ulp on a few elements at most
         assert torch.allclose(u, v, rtol=2.0 ** -7, atol=2e-3) and (u != v).float().mean().item() < 2e-2
     assert torch.allclose(s0, s1, rtol=1e-5)
