@@ -808,9 +808,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(GemmArgs g) {
 static constexpr int kPanelRows = 264;                       // 33 DMA groups of 8 rows
 static constexpr int kPanelBytes = kPanelRows * 128;
 
+// (T = float: the fp32 mode's split-bf16 form -- fp32 panels and B tiles of 32 k per row, fragments split in registers, mfma_x3)
+template <typename T>
 __global__ __launch_bounds__(512, 2) void gemm_nt_big_halo3_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef bf16_t T;
+  constexpr bool X3 = sizeof(T) == 4;
+  constexpr int EPC = 16 / (int)sizeof(T);                     // elements per 16-B chunk; a row of a stage is 8 chunks = 128 B of k
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -824,7 +827,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_halo3_kernel(GemmArgs g) {
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
   const int L = g.rm.Lout;
   const int pos0 = m0 % L;                                   // position of the tile's first row inside its sample
-  const int ksteps = g.K / 64;
+  const int ksteps = g.K / (8 * EPC);
 
   // A panel: group gi (8 rows) of wave w is 4 w + i, i < 4; wave 0 also loads group 32 (rows 256 .. 263, of which 256 and 257 are read)
   const char* pa[5];
@@ -835,7 +838,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_halo3_kernel(GemmArgs g) {
     const int pos = pos0 - 1 + r;
     const bool ok = r < 258 && pos >= 0 && pos < L;
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    pa[i] = ok ? reinterpret_cast<const char*>(A + (long)(m0 - 1 + r) * g.lda + c * 8) : zero;
+    pa[i] = ok ? reinterpret_cast<const char*>(A + (long)(m0 - 1 + r) * g.lda + c * EPC) : zero;
     ia[i] = ok ? 128 : 0;
   }
   // B tiles: this lane's row of W for DMA instruction i, tap 0, K-step 0
@@ -846,7 +849,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_halo3_kernel(GemmArgs g) {
     const int row = (wave * 4 + i) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     b_ok[i] = n0 + row < g.N;
-    pb[i] = b_ok[i] ? reinterpret_cast<const char*>(W + (long)(n0 + row) * g.ldw + c * 8) : zero;
+    pb[i] = b_ok[i] ? reinterpret_cast<const char*>(W + (long)(n0 + row) * g.ldw + c * EPC) : zero;
   }
   const long tapb = g.tapstride * (long)sizeof(T);
   char* panels = smem;
@@ -886,6 +889,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_halo3_kernel(GemmArgs g) {
       const char* sb = bring + slot * 32768;
       const bool more = t < 2 || more_k;
       const int tn = t < 2 ? t + 1 : 0, kn = t < 2 ? kb : kb + 1;
+      if constexpr (X3) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          if (more) { issue_b(slot ^ 1, 2 * ks, tn, kn); issue_b(slot ^ 1, 2 * ks + 1, tn, kn); }
+          if (more_k) {
+            if (t == 0) issue_a((kb + 1) & 1, ks);
+            if (t == 1 && ks == 0) issue_a((kb + 1) & 1, 2);
+            if (t == 2 && ks == 0) issue_a((kb + 1) & 1, 3);
+            if (t == 2 && ks == 1 && wave == 0) issue_a((kb + 1) & 1, 4);
+          }
+          bf16x8 ah[4], al[4], bh[2], bl[2];
+          auto frag = [&](const char* base, int row, bf16x8& hi, bf16x8& lo) {      // k = 16 ks + 8 lh + 0..7 of this lane's row
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(base + swz_off(row, 4 * ks + 2 * lh));
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(base + swz_off(row, 4 * ks + 2 * lh + 1));
+            const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            split_bf16x8(x, hi, lo);
+          };
+#pragma unroll
+          for (int i = 0; i < 4; ++i) frag(pan, wr * 128 + i * 32 + lr + t, ah[i], al[i]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) frag(sb, wc * 64 + j * 32 + lr, bh[j], bl[j]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mfma_x3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
+        }
+      } else {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (more) issue_b(slot ^ 1, ks, tn, kn);
@@ -906,6 +936,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_halo3_kernel(GemmArgs g) {
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+      }
       }
       __syncthreads();
     }
@@ -1990,12 +2021,14 @@ static int gemm_nt_launch(int dtype, const void* A, long lda, const void* W, lon
     const long tm = (M + kBig - 1) / kBig, tn = (N + kBig - 1) / kBig;
     const int dbg = getenv("OSUF_GEMM_DBG") ? atoi(getenv("OSUF_GEMM_DBG")) : 0;
     const dim3 grid_big((int)(((tm + 7) / 8) * 8 * tn));
-    const bool halo3 = dtype == OSUF_DT_BF16 && taps == 3 && mode == 0 && stride == 1 && pad == 1 && Lin == Lout && Lout % kBig == 0 && K % 64 == 0 &&
+    const bool halo3 = taps == 3 && mode == 0 && stride == 1 && pad == 1 && Lin == Lout && Lout % kBig == 0 && K % (dtype == OSUF_DT_BF16 ? 64 : 32) == 0 &&
                        dbg == 0 && getenv("OSUF_GEMM_NOHALO") == nullptr;
     if (halo3) {
-      static bool halo_attr = ((void)hipFuncSetAttribute((const void*)gemm_nt_big_halo3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big), true);
+      static bool halo_attr = ((void)hipFuncSetAttribute((const void*)gemm_nt_big_halo3_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big),
+                               (void)hipFuncSetAttribute((const void*)gemm_nt_big_halo3_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big), true);
       (void)halo_attr;
-      hipLaunchKernelGGL(gemm_nt_big_halo3_kernel, grid_big, dim3(512), lds_big, stream, g);
+      if (dtype == OSUF_DT_BF16) hipLaunchKernelGGL(gemm_nt_big_halo3_kernel<bf16_t>, grid_big, dim3(512), lds_big, stream, g);
+      else hipLaunchKernelGGL(gemm_nt_big_halo3_kernel<float>, grid_big, dim3(512), lds_big, stream, g);
     } else if (dtype == OSUF_DT_F32X3) hipLaunchKernelGGL((gemm_nt_big_kernel<float, 0, true>), grid_big, dim3(512), lds_big, stream, g);
     else if (dbg == 1) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 1>), grid_big, dim3(512), lds_big, stream, g);
     else if (dbg == 2) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 2>), grid_big, dim3(512), lds_big, stream, g);
