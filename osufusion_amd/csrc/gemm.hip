@@ -1681,6 +1681,124 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_taps3_kernel(WgradArgs g) {
   }
 }
 
+// The same three-taps-per-workgroup weight gradient for OSUF_DT_F32X3: fp32 stages of 64 rows of m (dY tile [64][128] + X panel of 66
+// rows, 512 B per row, one LDS-DMA instruction per two rows), fragments gathered down the columns -- dY with one ds_read_b64 per row (the
+// lane's k-element for both M-tiles: tile i owns the columns congruent i mod 2), X with ten ds_read_b32 per k-step that serve all three
+// taps' 8-row windows -- split into bf16 hi + lo in registers, three bf16 MFMAs per product.
+__global__ __launch_bounds__(512, 2) void gemm_tn_taps3_x3_kernel(WgradArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKM = 64, ROWB = 512, YB = BKM * ROWB, XROWS = 66, STAGE = YB + XROWS * ROWB;      // 32 KiB + 33 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n2 = (g.N2 + 127) / 128, tiles_n1 = (g.N1 + 127) / 128;
+  const int ntile = tiles_n1 * tiles_n2;
+  const int split = blockIdx.x / ntile, tile = blockIdx.x % ntile;
+  const int n1_0 = (tile / tiles_n2) * 128, n2_0 = (tile % tiles_n2) * 128;
+  const int m_begin = split * g.rows_per_split;
+  const int m_end = min(g.M, m_begin + g.rows_per_split);
+  if (m_begin >= m_end) return;
+  const float* dY = reinterpret_cast<const float*>(g.dY);
+  const float* X = reinterpret_cast<const float*>(g.X);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  const int L = g.rm.Lout;
+  // DMA: an instruction moves 2 rows x 512 B; instruction i < 4 of wave w is rows (4 w + i) * 2 + (lane >> 5), this lane its 16-B chunk
+  // lane & 31 (4 columns); wave 0's fifth X instruction is panel rows 64, 65
+  const int col = (lane & 31) * 4;
+  const bool y_ok = n1_0 + col < g.N1, x_ok = n2_0 + col < g.N2;
+  int pos = m_begin % L;
+  auto issue = [&](int mb, int buf) {
+    char* sy = smem + buf * STAGE;
+    char* sx = sy + YB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mb + (wave * 4 + i) * 2 + (lane >> 5);
+      const char* qy = (m < m_end && y_ok) ? reinterpret_cast<const char*>(dY + (long)m * g.ldy + n1_0 + col) : zero;
+      __builtin_amdgcn_global_load_lds((gas_ptr)qy, (las_ptr)(sy + (wave * 4 + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      if (i == 4 && wave != 0) break;
+      const int gi = i < 4 ? wave * 4 + i : 32;
+      const int pr = gi * 2 + (lane >> 5);                     // panel row pr = X row mb - 1 + pr
+      const int q = pos - 1 + pr;
+      const bool ok = q >= 0 && q < L && mb - 1 + pr < g.M && x_ok;
+      const char* qx = ok ? reinterpret_cast<const char*>(X + (long)(mb - 1 + pr) * g.ldx + n2_0 + col) : zero;
+      __builtin_amdgcn_global_load_lds((gas_ptr)qx, (las_ptr)(sx + gi * 1024), 16, 0, 0);
+    }
+    pos += BKM;
+    if (pos >= L) pos -= L;
+  };
+
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  issue(m_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  for (int mb = m_begin; mb < m_end; mb += BKM, buf ^= 1) {
+    if (mb + BKM < m_end) issue(mb + BKM, buf ^ 1);
+    const char* sy = smem + buf * STAGE;
+    const char* sx = sy + YB;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 ah[2], al[2], bh[3], bl[3];
+      {
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        f32x2 y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = *reinterpret_cast<const f32x2*>(sy + (16 * kk + 8 * lh + e) * ROWB + (wr * 64 + 2 * lr) * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float x[8] = {y[0][i], y[1][i], y[2][i], y[3][i], y[4][i], y[5][i], y[6][i], y[7][i]};
+          split_bf16x8(x, ah[i], al[i]);
+        }
+      }
+      {
+        float xw[10];                                          // panel rows 16 kk + 8 lh + 0 .. 9 of this lane's column: tap t's window starts at t
+#pragma unroll
+        for (int e = 0; e < 10; ++e) xw[e] = *reinterpret_cast<const float*>(sx + (16 * kk + 8 * lh + e) * ROWB + (wc * 32 + lr) * 4);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const float x[8] = {xw[t], xw[t + 1], xw[t + 2], xw[t + 3], xw[t + 4], xw[t + 5], xw[t + 6], xw[t + 7]};
+          split_bf16x8(x, bh[t], bl[t]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) mfma_x3(acc[i][t], ah[i], al[i], bh[t], bl[t]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float* out = g.ws ? g.ws + ((long)split * 3 + t) * g.N1 * g.N2 : g.dW + (long)t * g.tapstride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int n2 = n2_0 + wc * 32 + lr;
+      if (n2 < g.N2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n1 = n1_0 + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + i;
+          if (n1 < g.N1) {
+            if (g.ws) out[(long)n1 * g.N2 + n2] = acc[i][t][r];
+            else atomic_add_f32(out + (long)n1 * g.ldw + (long)n2 * g.es, acc[i][t][r]);
+          }
+        }
+      }
+    }
+  }
+}
+
 // deterministic second stage of the split wgrad: dW (+)= sum_s ws[s][t][i], i = n1*N2 + n2.
 // LAYOUT 0: dW[t][i] (the kernel's own order)   LAYOUT 1: dW[i][t] = torch's (Cout, Cin, k) conv weight layout -- the permute
 // is free here: a thread owns one i and writes its `taps` values contiguously.
@@ -2110,7 +2228,7 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
     hipLaunchKernelGGL(gemm_tn_skinny_kernel, dim3(tiles_n1 * taps * sp), dim3(512), lds_sk, stream, gs);
     return osuf_launch_status();
   }
-  if (splits <= 0 && dtype == OSUF_DT_BF16 && taps == 3 && mode == 0 && stride == 1 && pad == 1 && Lin == Lout && Lout % 128 == 0 && N1 >= 64 &&
+  if (splits <= 0 && (dtype == OSUF_DT_BF16 || dtype == OSUF_DT_F32X3) && taps == 3 && mode == 0 && stride == 1 && pad == 1 && Lin == Lout && Lout % 128 == 0 && N1 >= 64 &&
       N2 >= 64 && tn_big_plan(dtype, M, N1, N2, taps, nullptr, nullptr) && getenv("OSUF_GEMM_NOHALO") == nullptr) {
     // the three taps in one workgroup (gemm_tn_taps3_kernel): 128 x 128 tiles, about one round of the 256 CUs
     const int btiles = ((N1 + 127) / 128) * ((N2 + 127) / 128);
@@ -2129,9 +2247,11 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
     gb.es = es;
     if (!gb.ws && !accumulate) (void)hipMemsetAsync(dW, 0, (size_t)n * sizeof(float), stream);    // atomic path needs zeros
     const int lds_t3 = 2 * (128 * 256 + 132 * 256);
-    static bool t3_attr = ((void)hipFuncSetAttribute((const void*)gemm_tn_taps3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_t3), true);
+    static bool t3_attr = ((void)hipFuncSetAttribute((const void*)gemm_tn_taps3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_t3),
+                           (void)hipFuncSetAttribute((const void*)gemm_tn_taps3_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_t3), true);
     (void)t3_attr;
-    hipLaunchKernelGGL(gemm_tn_taps3_kernel, dim3(sp * btiles), dim3(512), lds_t3, stream, gb);
+    if (dtype == OSUF_DT_F32X3) hipLaunchKernelGGL(gemm_tn_taps3_x3_kernel, dim3(sp * btiles), dim3(512), lds_t3, stream, gb);
+    else hipLaunchKernelGGL(gemm_tn_taps3_kernel, dim3(sp * btiles), dim3(512), lds_t3, stream, gb);
     if (gb.ws) {
       const long n12 = (long)N1 * N2;
       const long groups = out_layout == 1 ? n12 / 4 : n / 4;
