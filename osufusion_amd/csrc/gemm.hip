@@ -1071,6 +1071,7 @@ struct WgradArgs {
   int M, N1, N2, taps;
   RowMap rm;
   int rows_per_split;
+  int xcd_chunks;                  // 256x256 wgrad kernels: unit list dealt to the XCDs in eighths (1) or round-robin (0: A/B switch OSUF_TN_RR)
 };
 
 // bf16 tile: [64 rows][128 cols] (256 B/row), byte-in-row ^= (row&3)<<6 -> ds_read_b64_tr_b16 conflict-free
@@ -1306,7 +1307,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(WgradArgs g) {
   // so they share one XCD's L2 and run back to back, and deal the units themselves round-robin over the 8 XCDs.
   const int ntile = tiles_n1 * tiles_n2;
   const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;
-  const int unit = (qid / g.taps) * 8 + xcd;
+  // (units are (split, tile) pairs, split-major: XCD x takes the x-th eighth of the list, so the tiles of one m-split -- which re-read the
+  //  same dY / X rows -- and their taps run back to back on one XCD.  The first form, unit = (qid / taps) * 8 + xcd, dealt a split's tiles
+  //  to eight different L2s: PMC FETCH_SIZE of these launches summed to 4.5 TB/s HBM-side, twice the algorithmic bytes.)
+  const int unit = g.xcd_chunks ? xcd * (((int)gridDim.x >> 3) / g.taps) + qid / g.taps : (qid / g.taps) * 8 + xcd;
   const int t = qid % g.taps;
   const int split = unit / ntile, tile = unit % ntile;
   const int n1_0 = (tile / tiles_n2) * kBig, n2_0 = (tile % tiles_n2) * kBig;
@@ -1444,7 +1448,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_x3_kernel(WgradArgs g) {
   const int tiles_n1 = (g.N1 + kBig - 1) / kBig;
   const int ntile = tiles_n1 * tiles_n2;                        // block -> (split, tile, tap) as in gemm_tn_big_kernel
   const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;
-  const int unit = (qid / g.taps) * 8 + xcd;
+  const int unit = g.xcd_chunks ? xcd * (((int)gridDim.x >> 3) / g.taps) + qid / g.taps : (qid / g.taps) * 8 + xcd;
   const int t = qid % g.taps;
   const int split = unit / ntile, tile = unit % ntile;
   const int n1_0 = (tile / tiles_n2) * kBig, n2_0 = (tile % tiles_n2) * kBig;
@@ -1556,7 +1560,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_taps3_kernel(WgradArgs g) {
   const int wr = wave >> 2, wc = wave & 3;
   const int tiles_n2 = (g.N2 + 127) / 128, tiles_n1 = (g.N1 + 127) / 128;
   const int ntile = tiles_n1 * tiles_n2;
-  const int split = blockIdx.x / ntile, tile = blockIdx.x % ntile;
+  // XCD-aware order (speed only): the tiles of one m-split re-read the same dY / X rows.  Block ids are dealt round-robin to the 8 XCDs, so
+  // XCD x takes the x-th eighth of the (split-major) unit list: a split's tiles run back to back on one XCD and meet in its L2
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int unit = xcd * ((int)gridDim.x >> 3) + local;
+  const int split = unit / ntile, tile = unit % ntile;
   const int n1_0 = (tile / tiles_n2) * 128, n2_0 = (tile % tiles_n2) * 128;
   const int m_begin = split * g.rows_per_split;
   const int m_end = min(g.M, m_begin + g.rows_per_split);
@@ -1693,7 +1701,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_taps3_x3_kernel(WgradArgs g) {
   const int wr = wave >> 2, wc = wave & 3;
   const int tiles_n2 = (g.N2 + 127) / 128, tiles_n1 = (g.N1 + 127) / 128;
   const int ntile = tiles_n1 * tiles_n2;
-  const int split = blockIdx.x / ntile, tile = blockIdx.x % ntile;
+  // XCD-aware order (speed only): the tiles of one m-split re-read the same dY / X rows.  Block ids are dealt round-robin to the 8 XCDs, so
+  // XCD x takes the x-th eighth of the (split-major) unit list: a split's tiles run back to back on one XCD and meet in its L2
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int unit = xcd * ((int)gridDim.x >> 3) + local;
+  const int split = unit / ntile, tile = unit % ntile;
   const int n1_0 = (tile / tiles_n2) * 128, n2_0 = (tile % tiles_n2) * 128;
   const int m_begin = split * g.rows_per_split;
   const int m_end = min(g.M, m_begin + g.rows_per_split);
@@ -2207,7 +2219,7 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
   const int bkm = dtype == OSUF_DT_BF16 ? 64 : 32;
   const bool noskinny = getenv("OSUF_GEMM_NOSKINNY") != nullptr;
   if (!noskinny && splits <= 0 && dtype == OSUF_DT_BF16 && N2 <= 32 && M >= 4096) {
-    WgradArgs gs;
+    WgradArgs gs{};
     gs.dY = dY; gs.X = X; gs.dW = dW; gs.ws = nullptr; gs.es = es; gs.ldy = ldy; gs.ldx = ldx; gs.ldw = ldw; gs.tapstride = tapstride;
     gs.M = M; gs.N1 = N1; gs.N2 = N2; gs.taps = taps; gs.rm = RowMap{Lin, Lout, stride, pad, mode};
     const int tiles_n1 = (N1 + kBig - 1) / kBig;
@@ -2237,7 +2249,7 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
     int rows = (M + sp - 1) / sp;
     rows = ((rows + 127) / 128) * 128;
     sp = (M + rows - 1) / rows;
-    WgradArgs gb;
+    WgradArgs gb{};
     gb.dY = dY; gb.X = X; gb.dW = dW; gb.ldy = ldy; gb.ldx = ldx; gb.ldw = ldw; gb.tapstride = tapstride;
     gb.M = M; gb.N1 = N1; gb.N2 = N2; gb.taps = taps; gb.rm = RowMap{Lin, Lout, stride, pad, mode};
     gb.rows_per_split = rows;
@@ -2250,8 +2262,9 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
     static bool t3_attr = ((void)hipFuncSetAttribute((const void*)gemm_tn_taps3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_t3),
                            (void)hipFuncSetAttribute((const void*)gemm_tn_taps3_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_t3), true);
     (void)t3_attr;
-    if (dtype == OSUF_DT_F32X3) hipLaunchKernelGGL(gemm_tn_taps3_x3_kernel, dim3(sp * btiles), dim3(512), lds_t3, stream, gb);
-    else hipLaunchKernelGGL(gemm_tn_taps3_kernel, dim3(sp * btiles), dim3(512), lds_t3, stream, gb);
+    const dim3 grid_t3(((sp * btiles + 7) / 8) * 8);
+    if (dtype == OSUF_DT_F32X3) hipLaunchKernelGGL(gemm_tn_taps3_x3_kernel, grid_t3, dim3(512), lds_t3, stream, gb);
+    else hipLaunchKernelGGL(gemm_tn_taps3_kernel, grid_t3, dim3(512), lds_t3, stream, gb);
     if (gb.ws) {
       const long n12 = (long)N1 * N2;
       const long groups = out_layout == 1 ? n12 / 4 : n / 4;
@@ -2269,10 +2282,11 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
   {
     int rows, sp;
     if (splits <= 0 && tn_big_plan(dtype, M, N1, N2, taps, &rows, &sp)) {
-      WgradArgs gb;
+      WgradArgs gb{};
       gb.dY = dY; gb.X = X; gb.dW = dW; gb.ldy = ldy; gb.ldx = ldx; gb.ldw = ldw; gb.tapstride = tapstride;
       gb.M = M; gb.N1 = N1; gb.N2 = N2; gb.taps = taps; gb.rm = RowMap{Lin, Lout, stride, pad, mode};
       gb.rows_per_split = rows;
+      gb.xcd_chunks = getenv("OSUF_TN_RR") == nullptr;
       const long n = (long)taps * N1 * N2;
       const bool dense = (out_layout == 1 && ((long)N1 * N2) % 4 == 0) || (out_layout == 0 && ldw == N2 && (taps == 1 || tapstride == (long)N1 * N2) && n % 4 == 0 && aligned16(dW));
       gb.ws = (workspace && dense && aligned16(workspace) && workspace_bytes >= (long)sp * n * (long)sizeof(float)) ? workspace : nullptr;
@@ -2310,7 +2324,7 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
   int rows = (M + splits - 1) / splits;
   rows = ((rows + bkm - 1) / bkm) * bkm;
   splits = (M + rows - 1) / rows;
-  WgradArgs g;
+  WgradArgs g{};
   g.dY = dY; g.X = X; g.dW = dW; g.ldy = ldy; g.ldx = ldx; g.ldw = ldw; g.tapstride = tapstride;
   g.M = M; g.N1 = N1; g.N2 = N2; g.taps = taps; g.rm = RowMap{Lin, Lout, stride, pad, mode};
   g.rows_per_split = rows;
