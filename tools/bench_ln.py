@@ -1,0 +1,21 @@
+"""LayerNorm forward / backward at the UNet's shapes: time and HBM-side GB/s (algorithmic bytes).  python tools/bench_ln.py"""
+import sys
+sys.path.insert(0, "/root/repo")
+import torch
+from osufusion_amd import ops
+def timeit(fn, iters=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+for M, C in ((131072, 256), (65536, 512), (32768, 768), (16384, 1024)):
+    x = torch.randn(M, C, device="cuda").bfloat16(); dy = torch.randn(M, C, device="cuda").bfloat16()
+    g = torch.randn(C, device="cuda"); b = torch.randn(C, device="cuda")
+    out, mr = ops.ln_fwd(x, g, b)
+    dg = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
+    t1 = timeit(lambda: ops.ln_fwd(x, g, b))
+    t2 = timeit(lambda: ops.ln_bwd(dy, x, mr, g, dg, db))
+    print(f"M={M:6d} C={C:4d}  fwd {t1*1e3:6.1f} us {M*C*4/t1/1e6:6.0f} GB/s | bwd {t2*1e3:6.1f} us {M*C*6/t2/1e6:6.0f} GB/s", flush=True)
