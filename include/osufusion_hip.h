@@ -75,6 +75,13 @@ int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, long ldx, f
                  int M, int N1, int N2, int taps, int Lin, int Lout, int stride, int pad, int mode,
                  int splits, int out_layout, int accumulate, float* workspace, long workspace_bytes, hipStream_t stream);
 long osuf_gemm_tn_workspace_bytes(int dtype, int M, int N1, int N2, int taps);
+/* osuf_gemm_tn + the bias gradient of the same layer from the same pass over dY: dbias[n1] += sum_m dY[m][n1] (fp32, N1 entries).  The
+ * bf16 256x256 and merged-taps kernels sum the dY fragments they hold anyway; every other path (fp32 modes, small shapes) runs osuf_colsum
+ * on dY itself (then N1 % 8 == 0 is required).
+ * replaces: autograd's weight- and bias-gradient of one Conv1d / Linear (residual.py:70,115, unet.py:118-123,149-156). */
+int osuf_gemm_tn_bias(int dtype, const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, long tapstride,
+                      int M, int N1, int N2, int taps, int Lin, int Lout, int stride, int pad, int mode,
+                      int splits, int out_layout, int accumulate, float* workspace, long workspace_bytes, float* dbias, hipStream_t stream);
 
 /* out[n] += sum_m Y[m][n]     replaces: autograd's bias-gradient of Conv1d / Linear. */
 int osuf_colsum(int dtype, const void* Y, long ldy, int M, int N, float* out, hipStream_t stream);

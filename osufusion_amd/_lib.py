@@ -22,6 +22,7 @@ SIGNATURES = {
     "osuf_gemm_nt": [I, P, L, P, L, L, P, L, P, L, P, L, P, L, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "osuf_gemm_nt_rowdot": [I, P, L, P, L, P, L, P, L, P, I, I, I, I, I, P],
     "osuf_gemm_tn": [I, P, L, P, L, P, L, L, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P],
+    "osuf_gemm_tn_bias": [I, P, L, P, L, P, L, L, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P, P],
     "osuf_gemm_tn_workspace_bytes": [I, I, I, I, I],
     "osuf_colsum": [I, P, L, I, I, P, P],
     "osuf_gn_finalize": [P, P, I, L, P],

@@ -1071,6 +1071,7 @@ struct WgradArgs {
   int M, N1, N2, taps;
   RowMap rm;
   int rows_per_split;
+  float* dbias;                    // optional: column sums of dY (the bias gradient) += , from the dY fragments the kernel already holds
   int xcd_chunks;                  // 256x256 wgrad kernels: unit list dealt to the XCDs in eighths (1) or round-robin (0: A/B switch OSUF_TN_RR)
 };
 
@@ -1293,6 +1294,18 @@ __device__ __forceinline__ void tn_big_store(const WgradArgs& g, const f32x16 (&
 // ds_read_b64_tr_b16 fragment reads conflict-free.  The transposed reads are issued through inline asm (hipcc guards the
 // ds_read_tr16 intrinsic with vmcnt(0) while an LDS-DMA is in flight) and software-pipelined one k-step ahead of the MFMAs.
 // ---------------------------------------------------------------------------------------------------------
+// sum of the 8 bf16 of an A-operand fragment (two 8-byte halves), added to acc: v_dot2c_f32_bf16 against (1, 1).
+// (The words are taken out of the vectors as scalars first: `__builtin_bit_cast(bf2, lo[1])` on a `const u32x2&` made hipcc use word 0
+//  twice -- rows 0, 1 counted double, rows 2, 3 never; found by the row-indicator case of the parity test.)
+__device__ __forceinline__ float bf16x2_sum(unsigned w, float acc) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, w), __builtin_bit_cast(bf2, 0x3F803F80u), acc, false);
+}
+__device__ __forceinline__ float bf16x8_sum(u32x2 lo, u32x2 hi, float acc) {
+  const unsigned w0 = lo.x, w1 = lo.y, w2 = hi.x, w3 = hi.y;
+  return bf16x2_sum(w3, bf16x2_sum(w2, bf16x2_sum(w1, bf16x2_sum(w0, acc))));
+}
+
 #define OSUF_TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
 __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(WgradArgs g) {
@@ -1403,6 +1416,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(WgradArgs g) {
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, vb), acc[i][j], 0, 0, 0); \
   }
 
+  // bias gradient (g.dbias): the column sums of dY are the row sums of the dY^T fragments this wave holds anyway -- one wave column of
+  // the workgroups of the first n2 tile and tap adds them up (4 v_dot2c per fragment), replacing a separate pass over dY (osuf_colsum)
+  const bool do_bias = g.dbias != nullptr && n2_0 == 0 && t == 0 && wc == 0;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#define TN_BIAS(slot)                                                                                             \
+  if (do_bias) { _Pragma("unroll") for (int i = 0; i < 4; ++i) bsum[i] = bf16x8_sum(fa[slot][i][0], fa[slot][i][1], bsum[i]); }
   issue(m_begin, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -1415,20 +1434,33 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_big_kernel(WgradArgs g) {
     TN_READS(1, 1, base)
     TN_WAIT(0, 12)
     TN_MFMA(0)
+    TN_BIAS(0)
     TN_READS(0, 2, base)
     TN_WAIT(1, 12)
     TN_MFMA(1)
+    TN_BIAS(1)
     TN_READS(1, 3, base)
     TN_WAIT(0, 12)
     TN_MFMA(0)
+    TN_BIAS(0)
     TN_WAIT(1, 0)
     TN_MFMA(1)
+    TN_BIAS(1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
 #undef TN_READS
 #undef TN_WAIT
 #undef TN_MFMA
+#undef TN_BIAS
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);        // the two k halves of the fragment rows
+      const int n1 = n1_0 + wr * 128 + i * 32 + lr;
+      if (lh == 0 && n1 < g.N1) atomic_add_f32(g.dbias + n1, v);
+    }
+  }
 
   tn_big_store(g, acc, split, t, n1_0, n2_0, wr, wc, lr, lh);
 }
@@ -1644,6 +1676,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_taps3_kernel(WgradArgs g) {
     acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), __builtin_bit_cast(bf16x8, vb), acc[i][t], 0, 0, 0); \
   }
 
+  const bool do_bias = g.dbias != nullptr && n2_0 == 0 && wc == 0;      // (see gemm_tn_big_kernel)
+  float bsum[2] = {0.f, 0.f};
+#define T3_BIAS(slot)                                                                                             \
+  if (do_bias) { _Pragma("unroll") for (int i = 0; i < 2; ++i) bsum[i] = bf16x8_sum(fa[slot][i][0], fa[slot][i][1], bsum[i]); }
   issue(m_begin, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -1653,20 +1689,29 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_taps3_kernel(WgradArgs g) {
     const uint32_t base = lds0 + buf * STAGE;
     T3_READS(0, 0, base)
     T3_READS(1, 1, base)
-    T3_WAIT(0, 10)  T3_MFMA(0)  T3_READS(0, 2, base)
-    T3_WAIT(1, 10)  T3_MFMA(1)  T3_READS(1, 3, base)
-    T3_WAIT(0, 10)  T3_MFMA(0)  T3_READS(0, 4, base)
-    T3_WAIT(1, 10)  T3_MFMA(1)  T3_READS(1, 5, base)
-    T3_WAIT(0, 10)  T3_MFMA(0)  T3_READS(0, 6, base)
-    T3_WAIT(1, 10)  T3_MFMA(1)  T3_READS(1, 7, base)
-    T3_WAIT(0, 10)  T3_MFMA(0)
-    T3_WAIT(1, 0)   T3_MFMA(1)
+    T3_WAIT(0, 10)  T3_MFMA(0)  T3_BIAS(0)  T3_READS(0, 2, base)
+    T3_WAIT(1, 10)  T3_MFMA(1)  T3_BIAS(1)  T3_READS(1, 3, base)
+    T3_WAIT(0, 10)  T3_MFMA(0)  T3_BIAS(0)  T3_READS(0, 4, base)
+    T3_WAIT(1, 10)  T3_MFMA(1)  T3_BIAS(1)  T3_READS(1, 5, base)
+    T3_WAIT(0, 10)  T3_MFMA(0)  T3_BIAS(0)  T3_READS(0, 6, base)
+    T3_WAIT(1, 10)  T3_MFMA(1)  T3_BIAS(1)  T3_READS(1, 7, base)
+    T3_WAIT(0, 10)  T3_MFMA(0)  T3_BIAS(0)
+    T3_WAIT(1, 0)   T3_MFMA(1)  T3_BIAS(1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
 #undef T3_READS
 #undef T3_WAIT
 #undef T3_MFMA
+#undef T3_BIAS
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+      const int n1 = n1_0 + wr * 64 + i * 32 + lr;
+      if (lh == 0 && n1 < g.N1) atomic_add_f32(g.dbias + n1, v);
+    }
+  }
 
   // partial tiles of this m-split ([split][tap][N1][N2], plain stores; summed by the wgrad_reduce kernels) or fp32 atomics into dW
 #pragma unroll
@@ -2204,9 +2249,13 @@ extern "C" long osuf_gemm_tn_workspace_bytes(int dtype, int M, int N1, int N2, i
   return (long)sp * taps * N1 * N2 * (long)sizeof(float);
 }
 
-extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, long tapstride,
-                            int M, int N1, int N2, int taps, int Lin, int Lout, int stride, int pad, int mode,
-                            int splits, int out_layout, int accumulate, float* workspace, long workspace_bytes, hipStream_t stream) {
+extern "C" int osuf_colsum(int dtype, const void* Y, long ldy, int M, int N, float* out, hipStream_t stream);
+
+// dbias (optional): += the column sums of dY (the bias gradient of the layer).  The bf16 256x256 and merged-taps kernels take them from the
+// dY fragments they hold anyway; every other path runs osuf_colsum on dY.
+static int gemm_tn_launch(int dtype, const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, long tapstride,
+                          int M, int N1, int N2, int taps, int Lin, int Lout, int stride, int pad, int mode,
+                          int splits, int out_layout, int accumulate, float* workspace, long workspace_bytes, float* dbias, hipStream_t stream) {
   // out_layout 0: dW[t][n1][n2] with (ldw, tapstride) as given; 1: dense torch conv layout dW[n1][n2][t] (ldw/tapstride ignored)
   long es = 1;
   if (out_layout == 1) { ldw = (long)N2 * taps; tapstride = 1; es = taps; }
@@ -2216,6 +2265,9 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
   if (M <= 0 || N1 <= 0 || N2 <= 0 || taps <= 0 || Lout <= 0 || Lin <= 0 || M % Lout) return OSUF_EINVAL;
   if (N1 % epc || N2 % epc || ldy % epc || ldx % epc) return OSUF_EINVAL;
   if (!aligned16(dY) || !aligned16(X)) return OSUF_EINVAL;
+  auto bias_by_colsum = [&]() -> int {                       // paths whose kernel does not produce the sums
+    return dbias ? osuf_colsum(dtype == OSUF_DT_BF16 ? OSUF_DT_BF16 : OSUF_DT_F32, dY, ldy, M, N1, dbias, stream) : OSUF_OK;
+  };
   const int bkm = dtype == OSUF_DT_BF16 ? 64 : 32;
   const bool noskinny = getenv("OSUF_GEMM_NOSKINNY") != nullptr;
   if (!noskinny && splits <= 0 && dtype == OSUF_DT_BF16 && N2 <= 32 && M >= 4096) {
@@ -2238,6 +2290,7 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
     static bool sk_attr = ((void)hipFuncSetAttribute((const void*)gemm_tn_skinny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_sk), true);
     (void)sk_attr;
     hipLaunchKernelGGL(gemm_tn_skinny_kernel, dim3(tiles_n1 * taps * sp), dim3(512), lds_sk, stream, gs);
+    if (int rc = bias_by_colsum()) return rc;
     return osuf_launch_status();
   }
   if (splits <= 0 && (dtype == OSUF_DT_BF16 || dtype == OSUF_DT_F32X3) && taps == 3 && mode == 0 && stride == 1 && pad == 1 && Lin == Lout && Lout % 128 == 0 && N1 >= 64 &&
@@ -2257,6 +2310,8 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
     const bool dense = (out_layout == 1 && ((long)N1 * N2) % 4 == 0) || (out_layout == 0 && ldw == N2 && tapstride == (long)N1 * N2 && n % 4 == 0 && aligned16(dW));
     gb.ws = (workspace && dense && aligned16(workspace) && workspace_bytes >= (long)sp * n * (long)sizeof(float)) ? workspace : nullptr;
     gb.es = es;
+    gb.dbias = dtype == OSUF_DT_BF16 ? dbias : nullptr;
+    if (dtype != OSUF_DT_BF16) { if (int rc = bias_by_colsum()) return rc; }
     if (!gb.ws && !accumulate) (void)hipMemsetAsync(dW, 0, (size_t)n * sizeof(float), stream);    // atomic path needs zeros
     const int lds_t3 = 2 * (128 * 256 + 132 * 256);
     static bool t3_attr = ((void)hipFuncSetAttribute((const void*)gemm_tn_taps3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_t3),
@@ -2291,6 +2346,8 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
       const bool dense = (out_layout == 1 && ((long)N1 * N2) % 4 == 0) || (out_layout == 0 && ldw == N2 && (taps == 1 || tapstride == (long)N1 * N2) && n % 4 == 0 && aligned16(dW));
       gb.ws = (workspace && dense && aligned16(workspace) && workspace_bytes >= (long)sp * n * (long)sizeof(float)) ? workspace : nullptr;
       gb.es = es;
+      gb.dbias = dtype == OSUF_DT_BF16 ? dbias : nullptr;
+      if (dtype != OSUF_DT_BF16) { if (int rc = bias_by_colsum()) return rc; }
       if (!gb.ws && !accumulate) (void)hipMemsetAsync(dW, 0, (size_t)n * sizeof(float), stream);    // atomic path needs zeros
       const int btiles = ((N1 + kBig - 1) / kBig) * ((N2 + kBig - 1) / kBig);
       const int lds_big = 2 * 65536;
@@ -2334,6 +2391,7 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
     if (out_layout == 0 && !(ldw == N2 && (taps == 1 || tapstride == (long)N1 * N2))) return OSUF_EINVAL;   // needs a dense dW to clear
     (void)hipMemsetAsync(dW, 0, (size_t)taps * N1 * N2 * sizeof(float), stream);
   }
+  if (int rc = bias_by_colsum()) return rc;
   const int lds = 4 * 16384;
   if (dtype == OSUF_DT_BF16) {
     hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, dim3(tiles, taps, splits), dim3(256), lds, stream, g);
@@ -2343,6 +2401,24 @@ extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, 
     hipLaunchKernelGGL(gemm_tn_kernel<float>, dim3(tiles, taps, splits), dim3(256), lds, stream, g);
   }
   return osuf_launch_status();
+}
+
+extern "C" int osuf_gemm_tn(int dtype, const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, long tapstride,
+                            int M, int N1, int N2, int taps, int Lin, int Lout, int stride, int pad, int mode,
+                            int splits, int out_layout, int accumulate, float* workspace, long workspace_bytes, hipStream_t stream) {
+  return gemm_tn_launch(dtype, dY, ldy, X, ldx, dW, ldw, tapstride, M, N1, N2, taps, Lin, Lout, stride, pad, mode, splits, out_layout, accumulate,
+                        workspace, workspace_bytes, nullptr, stream);
+}
+
+// osuf_gemm_tn + the bias gradient of the same layer: dbias[n1] += sum_m dY[m][n1] (fp32, N1 entries; needs N1 % 8 == 0 on the paths that
+// fall back to osuf_colsum)
+extern "C" int osuf_gemm_tn_bias(int dtype, const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, long tapstride,
+                                 int M, int N1, int N2, int taps, int Lin, int Lout, int stride, int pad, int mode,
+                                 int splits, int out_layout, int accumulate, float* workspace, long workspace_bytes, float* dbias,
+                                 hipStream_t stream) {
+  if (!dbias) return OSUF_EINVAL;
+  return gemm_tn_launch(dtype, dY, ldy, X, ldx, dW, ldw, tapstride, M, N1, N2, taps, Lin, Lout, stride, pad, mode, splits, out_layout, accumulate,
+                        workspace, workspace_bytes, dbias, stream);
 }
 
 extern "C" int osuf_colsum(int dtype, const void* Y, long ldy, int M, int N, float* out, hipStream_t stream) {

@@ -8,6 +8,8 @@ from __future__ import annotations
 import weakref
 from typing import Dict, Optional, Tuple
 
+import os
+
 import torch
 
 from . import ops
@@ -277,16 +279,33 @@ def conv_dgrad(dy, w, cache: PackCache, kind: str, Lin: int, residual=None, vp=N
     return ops.gemm_nt(dy, wp, None, lin=Lout, lout=Lin, residual=residual, out_shape=(B, Lin, Cin), **geom)
 
 
-def conv_wgrad(dy, x, w, kind: str, direct: bool = True):
+FUSE_BIAS_GRAD = os.environ.get("OSUF_NO_FUSED_BIAS") is None      # weight + bias gradient of a layer from one pass over dy (osuf_gemm_tn_bias); off: osuf_gemm_tn + osuf_colsum
+
+
+def conv_wgrad_bias(dy, x, w, kind: str, bias, need_w: bool, need_b: bool, n: Optional[int] = None):
+    """(dw, db) of one Conv1d / Linear.  When both are wanted and the bias has a direct .grad target, its column sums ride the weight
+    gradient's pass over dy; otherwise the two separate calls."""
+    if need_w and need_b and bias is not None and FUSE_BIAS_GRAD:
+        tgt = grad_target(bias)
+        if tgt is not None and tgt.numel() == w.shape[0]:
+            dw = conv_wgrad(dy, x, w, kind, bias_out=tgt)
+            grad_done(bias)
+            return dw, None
+    dw = conv_wgrad(dy, x, w, kind) if need_w else None
+    db = _bias_grad(dy, bias, n) if (need_b and bias is not None) else None
+    return dw, db
+
+
+def conv_wgrad(dy, x, w, kind: str, direct: bool = True, bias_out: Optional[torch.Tensor] = None):
     """Weight gradient in w's own layout: added straight into w.grad (returns None) when direct accumulation is on and w is a
-    leaf parameter with a dense fp32 .grad; otherwise a fresh tensor shaped like w."""
+    leaf parameter with a dense fp32 .grad; otherwise a fresh tensor shaped like w.  bias_out: see ops.gemm_tn."""
     B, Lin, Cin = x.shape
     conv = w.dim() == 3
     k = w.shape[2] if conv else 1
     Lout, stride, pad, mode = _conv_geom(kind, k, Lin)
     tgt = grad_target(w) if direct else None
     g = ops.gemm_tn(dy, x, taps=k, lin=Lin, lout=Lout, stride=stride, pad=pad, mode=mode, n1=w.shape[0], out=tgt, conv_layout=conv,
-                    accumulate=tgt is not None)
+                    accumulate=tgt is not None, bias_out=bias_out)
     if tgt is not None:
         grad_done(w)
         return None
@@ -405,8 +424,7 @@ class ConvFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy = _rc(dy)
         dx = conv_dgrad(dy, w, ctx.cache, ctx.kind, x.shape[1], vp=ctx.vp) if ctx.needs_input_grad[0] else None
-        dw = conv_wgrad(dy, x, w, ctx.kind) if ctx.needs_input_grad[1] else None
-        db = _bias_grad(dy, ctx.bias_ref, w.shape[0]) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dw, db = conv_wgrad_bias(dy, x, w, ctx.kind, ctx.bias_ref if ctx.has_bias else None, ctx.needs_input_grad[1], ctx.needs_input_grad[2], w.shape[0])
         return dx, dw, db, None, None, None
 
 
@@ -816,8 +834,7 @@ class GateResConvFn(torch.autograd.Function):
         dx = conv_dgrad(dout, w, ctx.cache, "same", L) if ctx.needs_input_grad[2] else None
         if ctx.rlink is not None and dx is not None:
             ctx.rlink.dx, dx = dx, None
-        dw = conv_wgrad(dout, x, w, "same") if ctx.needs_input_grad[3] else None
-        db = _bias_grad(dout, ctx.bias_ref) if ctx.needs_input_grad[4] else None
+        dw, db = conv_wgrad_bias(dout, x, w, "same", ctx.bias_ref, ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         return dh, dgate, dx, dw, db, None, None, None
 
 
@@ -841,10 +858,8 @@ class FeedForwardFn(torch.autograd.Function):
         wd2 = cache.packs(("p2", x.dtype), (w2,), w2, "same", x.dtype)[1]
         dpre = ops.gemm_nt(dout, wd2, None, dact=pre, out_shape=pre.shape)          # (dout W2) * silu'(pre)
         need = ctx.needs_input_grad
-        dw2 = conv_wgrad(dout, h, w2, "same") if need[3] else None
-        db2 = _bias_grad(dout, ctx.b2) if need[4] else None
-        dw1 = conv_wgrad(dpre, x, w1, "same") if need[1] else None
-        db1 = _bias_grad(dpre, ctx.b1) if need[2] else None
+        dw2, db2 = conv_wgrad_bias(dout, h, w2, "same", ctx.b2, need[3], need[4])
+        dw1, db1 = conv_wgrad_bias(dpre, x, w1, "same", ctx.b1, need[1], need[2])
         wd1 = cache.packs(("p", "same", x.dtype, ""), (w1,), w1, "same", x.dtype)[1]
         dx = ops.gemm_nt(dpre, wd1, None, residual=dout, out_shape=x.shape)
         return dx, dw1, db1, dw2, db2, None
@@ -921,8 +936,7 @@ class AttentionFn(torch.autograd.Function):
         dt = x.dtype
         dout = _rc(dout)
         # to_out
-        dwo = conv_wgrad(dout, o, wo, "same") if need[5] else None
-        dbo = _bias_grad(dout, ctx.bo) if need[6] else None
+        dwo, dbo = conv_wgrad_bias(dout, o, wo, "same", ctx.bo, need[5], need[6])
         wdo = cache.packs(("po", dt), (wo,) if ctx.base is None else (ctx.base[1],), wo, "same", dt)[1]
         if ops.FUSE_ROWDOT and G == 1 and D == 64:                             # (the epilogue sums 64-column heads)
             do, delta = ops.gemm_nt_rowdot(dout, wdo, o, N, H)                   # dO and sum_d dO * O from one epilogue

@@ -218,9 +218,10 @@ def gemm_nt_rowdot(a: torch.Tensor, w: torch.Tensor, o: torch.Tensor, L: int, he
 
 def gemm_tn(dy: torch.Tensor, x: torch.Tensor, *, taps: int = 1, lin: Optional[int] = None, lout: Optional[int] = None, stride: int = 1,
             pad: int = 0, mode: int = 0, n1: Optional[int] = None, out: Optional[torch.Tensor] = None, conv_layout: bool = False,
-            accumulate: bool = False) -> torch.Tensor:
+            accumulate: bool = False, bias_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """sum_m dY[m][n1] * X[rowmap(m,t)][n2] -> fp32.  Default result [taps][N1][N2]; conv_layout=True -> (N1, N2, taps), the layout
-    of a torch Conv1d weight.  `out` (dense fp32) is overwritten, or added into when accumulate=True (e.g. a parameter's .grad)."""
+    of a torch Conv1d weight.  `out` (dense fp32) is overwritten, or added into when accumulate=True (e.g. a parameter's .grad).
+    bias_out (fp32 (N1,)): += the column sums of dy, i.e. the layer's bias gradient, from the same pass (osuf_gemm_tn_bias)."""
     M, N1, ldy = _rows(dy)
     Mx, N2, ldx = _rows(x)
     if n1 is not None:
@@ -235,8 +236,13 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, *, taps: int = 1, lin: Optional[i
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == taps * N1 * N2
     need = _lib.load().osuf_gemm_tn_workspace_bytes(dt_of(dy), M, N1, N2, taps)
     ws = _workspace(need, dy.device) if need > 0 else None
-    call("osuf_gemm_tn", gemm_dt(dy), _p(dy), ldy, _p(x), ldx, _p(out), N2, N1 * N2, M, N1, N2, taps, lin, lout, stride, pad, mode, 0,
-         1 if conv_layout else 0, 1 if accumulate else 0, _p(ws), need if ws is not None else 0, _stream())
+    args = (gemm_dt(dy), _p(dy), ldy, _p(x), ldx, _p(out), N2, N1 * N2, M, N1, N2, taps, lin, lout, stride, pad, mode, 0,
+            1 if conv_layout else 0, 1 if accumulate else 0, _p(ws), need if ws is not None else 0)
+    if bias_out is not None:
+        assert bias_out.dtype == torch.float32 and bias_out.is_contiguous() and bias_out.numel() == N1
+        call("osuf_gemm_tn_bias", *args, _p(bias_out), _stream())
+    else:
+        call("osuf_gemm_tn", *args, _stream())
     return out
 
 

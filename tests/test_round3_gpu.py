@@ -451,3 +451,42 @@ def test_halo_shared_k3_conv_kernel(monkeypatch, Cin, Cout, L, Bq):
     assert relmax(p1.permute(0, 2, 1), ref) < 1e-2
     # a sample's first and last rows see zeros, not the neighbouring sample's rows
     assert relmax(p1[:, [0, L - 1]].permute(0, 2, 1), ref[:, :, [0, L - 1]]) < 1e-2
+
+
+@pytest.mark.parametrize("M,N1,N2,taps,force_big", [(1024, 328, 128, 3, True), (2048, 256, 64, 1, True), (4096, 1152, 256, 1, True),
+                                                     (520, 96, 40, 1, False), (1024, 328, 128, 3, False)])
+@pytest.mark.parametrize("dtype", ["bf16", "x3"])
+def test_bias_gradient_rides_the_weight_gradient(monkeypatch, M, N1, N2, taps, force_big, dtype):
+    """osuf_gemm_tn_bias: the layer's bias gradient (column sums of dy) from the weight gradient's own pass over dy -- the merged-taps and
+    256x256 bf16 kernels sum the dY fragments they hold, every other path (small shapes, the fp32 modes) runs osuf_colsum inside the entry
+    point.  Against dy.sum(0) in fp64 and against osuf_gemm_tn + osuf_colsum (residual.py:70,115, unet.py:118-123,149-156)."""
+    if force_big:
+        monkeypatch.setenv("OSUF_GEMM_BIG_MIN_TILES", "1")
+    torch.manual_seed(M + N1)
+    L = M // 2
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    dy = torch.randn(M, N1, device=DEV).to(dt)
+    x = torch.randn(M, N2, device=DEV).to(dt)
+    kw = dict(taps=taps, lin=L, lout=L, stride=1, pad=taps // 2, mode=0)
+    prev = ops.set_f32_matmul("x3")
+    try:
+        db = torch.full((N1,), 0.5, device=DEV)                      # accumulated into, not overwritten
+        gw = ops.gemm_tn(dy, x, bias_out=db, **kw)
+        gw0 = ops.gemm_tn(dy, x, **kw)
+    finally:
+        ops.set_f32_matmul(prev)
+    want = dy.double().sum(0) + 0.5
+    assert rell2(db, want) < 2e-6
+    assert torch.allclose(gw, gw0, rtol=1e-5, atol=1e-5 * gw0.abs().max().item())
+    assert rell2(ops.colsum(dy, N1) + 0.5, want) < 2e-6
+    # every row of m counted exactly once: indicator rows (a first version counted rows 0, 1 of each group of four twice and rows 2, 3 never,
+    # which random data and all-ones both let through at the magnitude level)
+    for r in (2, 3, 7, 13):
+        ind = (torch.arange(M, device=DEV) % 16 == r).to(dt)[:, None].expand(M, N1).contiguous()
+        db = torch.zeros(N1, device=DEV)
+        prev = ops.set_f32_matmul("x3")
+        try:
+            ops.gemm_tn(ind, x, bias_out=db, **kw)
+        finally:
+            ops.set_f32_matmul(prev)
+        assert torch.equal(db, ind.float().sum(0)), r
