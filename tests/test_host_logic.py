@@ -59,8 +59,11 @@ def emu_gemm_nt(a, w, bias=None, *, taps=1, n_out=None, lin=None, lout=None, str
     return C.reshape(out_shape) if out_shape is not None else C
 
 
-def emu_gemm_tn(dy, x, *, taps=1, lin=None, lout=None, stride=1, pad=0, mode=0, n1=None, out=None, conv_layout=False, accumulate=False):
+def emu_gemm_tn(dy, x, *, taps=1, lin=None, lout=None, stride=1, pad=0, mode=0, n1=None, out=None, conv_layout=False, accumulate=False,
+                bias_out=None):
     Y = dy.reshape(-1, dy.shape[-1]).double()
+    if bias_out is not None:                                   # osuf_gemm_tn_bias: += the column sums of dy
+        bias_out += Y.sum(0).float()
     X = x.reshape(-1, x.shape[-1]).double()
     if lin is None:
         lin = lout = Y.shape[0]
