@@ -132,6 +132,36 @@ def sampler_secondary(model, device):
                 note="eager launches (hipGraph replay of the step is bit-identical and no faster: GPU-bound); audio code cached, CFG as one 2B batch")
 
 
+CONFIG5_B, CONFIG5_R = 64, 16
+
+
+def config5_secondary(model, rank: int, device):
+    """BASELINE config 5's per-GPU shard on the driver's clock (global batch 512 on 8 GPUs = 64 per GPU; trainer_peft.py:236-244 with
+    r = 16 as config 5 says): the SAME weights, frozen, DoRA adapters on attn.to_q / to_kv / block1.proj / block2.proj, one warm-up
+    and two timed train steps (fwd + bwd of the adapters + clip + AdamW) at B=64, L=4096, bf16."""
+    from osufusion_amd.modules import lora_layers as LL
+    from osufusion_amd.train import Trainer
+    LL.get_peft_model(model, LL.LoraConfig(r=CONFIG5_R, lora_alpha=CONFIG5_R, use_dora=True))
+    with torch.no_grad():                                  # peft zero-inits lora_B: give it life so every adapter gradient is exercised
+        for m in LL.lora_modules(model):
+            m.lora_B["default"].weight.normal_(0.0, 0.02)
+    n_train, n_all = LL.trainable_parameter_counts(model)
+    trainer = Trainer(model, lr=1e-4, weight_decay=1e-2, clip_grad_norm=1.0, compute_dtype=torch.bfloat16)
+    x, a, c, noise, t = synth_batch(rank, device, CONFIG5_B, LENGTH)
+    trainer.step(x, a, c, noise, t)
+    torch.cuda.synchronize()
+    steps = 2
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, gnorm = trainer.step(x, a, c, noise, t)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return dict(metric=f"DoRA r={CONFIG5_R} fine-tune step at per-GPU B={CONFIG5_B} L={LENGTH} (BASELINE config 5's shard of global batch 512), 1 MI355X",
+                ms_per_step=round(1e3 * dt, 1), steps_per_s=round(1.0 / dt, 3), samples_per_s=round(CONFIG5_B / dt, 1), dtype="bf16",
+                trainable_params=int(n_train), total_params=int(n_all), loss=round(loss.item(), 5), grad_norm=round(gnorm.item(), 4),
+                finite=bool(torch.isfinite(loss).item() and torch.isfinite(gnorm).item()), timed_steps=steps, warmup=1)
+
+
 def cpu_model() -> str:
     try:
         for line in Path("/proc/cpuinfo").read_text().splitlines():
@@ -165,6 +195,7 @@ def main() -> None:
                          "block{1,2}.proj (trainer_peft.py:236-244), base frozen; the reference runs R=32, config 5 says 16")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-sampler", action="store_true", help="skip the secondary metric (one 50-step DDIM sample at BASELINE config 4's size)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the DoRA r=16, B=64 secondary (BASELINE config 5's per-GPU shard)")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the extra fp32-compute-mode step (the mode in which the 1e-3 parity bound holds)")
     ap.add_argument("--attn-bwd", choices=["auto", "pair", "fused", "fused256", "fused512", "slabs"], default="auto",
                     help="attention backward: auto = the library default (fused sweep, atomic dQ, 256 or 512 keys per workgroup by shape); "
@@ -285,7 +316,9 @@ def main() -> None:
             # the compute mode in which north_star's 1e-3 bound holds (exact-f32 MFMA everywhere, bf16 only where the reference casts):
             # one warm-up + one timed step, after the timed region; bf16 (timed above) sits at the reference's own autocast distance
             trainer.compute_dtype = torch.float32
-            for key, mm in (("fp32_mode_ms_per_step", "x3"), ("fp32_exact_mode_ms_per_step", "exact")):
+            # (key names: fp32_mode_ms_per_step is the EXACT-f32 mode in every round's record; round 3 printed the x3 mode under that key
+            #  and the exact one under fp32_exact_mode_ms_per_step, which is kept as an alias)
+            for key, mm in (("fp32x3_mode_ms_per_step", "x3"), ("fp32_mode_ms_per_step", "exact")):
                 prev = ops.set_f32_matmul(mm)              # x3: fp32 storage, GEMM products as three bf16 MFMAs on split operands (~17 bits);
                 try:                                       # exact: v_mfma_f32_32x32x2_f32, the reference's fp32 arithmetic bit for bit
                     trainer.step(x, a, c, noise, t)
@@ -296,14 +329,20 @@ def main() -> None:
                     out[key] = round(1e3 * (time.perf_counter() - t1), 1)
                 finally:
                     ops.set_f32_matmul(prev)
-            out["parity_note"] = ("bf16 (timed) is 0.9-1.3e-2 rel-L2 from the fp32 oracle = the oracle's own bf16-vs-fp32 distance; both fp32 "
-                                  "modes meet 1e-3 (tests/test_full_size.py, tests/test_round3_gpu.py): fp32_mode = x3 GEMMs, fp32_exact_mode = f32 MFMA")
+            out["fp32_exact_mode_ms_per_step"] = out["fp32_mode_ms_per_step"]
+            out["parity_note"] = ("bf16 (timed) is 0.9-1.3e-2 rel-L2 from the fp32 oracle = the oracle's own bf16-vs-fp32 distance; both fp32 modes "
+                                  "are held to 1e-3 at this size by tests/test_full_size.py (forward of two samples and all 1,239 gradients of one "
+                                  "sample, each run with set_f32_matmul('exact') and ('x3')): fp32x3_mode = split-bf16 GEMMs, fp32_mode = f32 MFMA")
         if world == 1 and not args.no_sampler and not args.lora and full:
             print("[bench] secondary: DDIM sample at config 4's size ...", file=sys.stderr, flush=True)
             out["secondary"] = sampler_secondary(model, device)
         if world == 1 and not args.no_cpu_baseline and not args.lora:
             out["cpu_baseline"] = cpu_baseline(model, args.length, args.cpu_threads or host_threads())
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        if world == 1 and not args.no_config5 and not args.lora and full:
+            print("[bench] config 5: DoRA r=16 steps at the per-GPU shard B=64 ...", file=sys.stderr, flush=True)
+            del trainer
+            out["config5"] = config5_secondary(model, rank, device)       # LAST: wraps the model's layers in place
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

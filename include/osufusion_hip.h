@@ -36,8 +36,9 @@ extern "C" {
 #define OSUF_DQ_ATOMIC 0          /* fp32 atomics; the sweep (256 or 512 keys per workgroup) is picked by shape */
 #define OSUF_DQ_SLABS 1
 #define OSUF_DQ_ATOMIC_256 2      /* force the 8-wave, 256-key sweep */
-#define OSUF_DQ_ATOMIC_512 3      /* force the 4-wave, 512-key sweep (N % 32 == 0, else -2) */
-#define OSUF_DQ_TIMING_512 4      /* the 512-key sweep WITHOUT its atomics: timing only, dq comes back zero */
+#define OSUF_DQ_ATOMIC_512 3      /* force the 4-wave, 512-key sweep (whole 512-key blocks: N % 512 == 0, else OSUF_EUNSUPPORTED) */
+#define OSUF_DQ_TIMING_512 4      /* DEBUG: the 512-key sweep WITHOUT its atomics (prices the loop; dq comes back zero) -- refused with
+                                     OSUF_EUNSUPPORTED unless the process environment holds OSUF_ALLOW_TIMING_BUILDS=1 */
 
 int osuf_version(void);
 

@@ -1795,8 +1795,12 @@ static long fused_dq_bytes(int B, int H, int N, int out_dtype, int dq_mode) {
 static bool fused_use512(int B, int N, int dq_mode) {
   if (dq_mode == OSUF_DQ_ATOMIC_512 || dq_mode == OSUF_DQ_TIMING_512) return true;
   if (dq_mode != OSUF_DQ_ATOMIC) return false;
-  return (N % 32) == 0 && N >= 1024;
+  // whole 512-key blocks only: a padded key's K / V rows are zero, but its S accumulator starts at -lse2 / c, so p = exp2(-lse2) and
+  // dS = p * (-delta) are not -- for a row with lse2 < -128 p overflows and inf x 0 lands in dQ as NaN
+  return (N % 512) == 0 && N >= 1024;
 }
+// the timing-only build returns OSUF_OK with dq all zeros: refused unless the caller's environment says it is pricing a loop
+static bool timing_builds_allowed() { const char* e = getenv("OSUF_ALLOW_TIMING_BUILDS"); return e && e[0] == '1'; }
 static int fused512_qsplit(int B, int N, int forced) {
   if (forced > 0) return forced;
   const int blocks = ((N + 511) / 512) * ((B + 7) / 8 * 8);
@@ -1828,7 +1832,8 @@ extern "C" int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long l
     return OSUF_EINVAL;
   if (head_dim != D) return OSUF_EUNSUPPORTED;                     // the fused sweeps are written for 64-wide heads (others: dq + dkv kernels)
   const bool use512 = fused_use512(B, N, dq_mode);
-  if (use512 && (N % 32) != 0) return OSUF_EUNSUPPORTED;           // the 512-key sweep is written for whole 32-query blocks
+  if (use512 && (N % 512) != 0) return OSUF_EUNSUPPORTED;          // the 512-key sweep is written for whole 512-key blocks (see fused_use512)
+  if (dq_mode == OSUF_DQ_TIMING_512 && !timing_builds_allowed()) return OSUF_EUNSUPPORTED;
   a.dk = dk; a.dv = dv; a.lddk = lddk; a.g_bf16 = out_dtype == OSUF_DT_BF16; a.rcos = rope_cos; a.rsin = rope_sin;
   const long M = (long)B * N;
   const long dq_bytes = fused_dq_bytes(B, H, N, out_dtype, dq_mode);

@@ -234,7 +234,7 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, *, taps: int = 1, lin: Optional[i
         assert not accumulate
         out = torch.empty(shape, dtype=torch.float32, device=dy.device)
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == taps * N1 * N2
-    need = _lib.load().osuf_gemm_tn_workspace_bytes(dt_of(dy), M, N1, N2, taps)
+    need = _lib.load().osuf_gemm_tn_workspace_bytes(gemm_dt(dy), M, N1, N2, taps)   # the dtype code the launch uses (x3 has split plans, exact f32 none)
     ws = _workspace(need, dy.device) if need > 0 else None
     args = (gemm_dt(dy), _p(dy), ldy, _p(x), ldx, _p(out), N2, N1 * N2, M, N1, N2, taps, lin, lout, stride, pad, mode, 0,
             1 if conv_layout else 0, 1 if accumulate else 0, _p(ws), need if ws is not None else 0)

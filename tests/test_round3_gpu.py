@@ -322,6 +322,19 @@ def test_f32x3_gemms_keep_seventeen_bits(monkeypatch, M, N, K, taps, big):
     assert errs["exact"][0] < 2e-6
     assert errs["x3"][0] < 3e-5 and e_w < 3e-5, (errs["x3"][0], e_w)
     assert e_bf > 30 * errs["x3"][0]
+    # the x3 weight gradient with a split plan goes through partial tiles in a workspace + the fixed-order reduce (ops.gemm_tn asks for the
+    # workspace with the launch's dtype code since round 4; with dt_of() it got none and fell back to fp32 atomics): bit-reproducible
+    from osufusion_amd import _lib
+    need = _lib.load().osuf_gemm_tn_workspace_bytes(ops.F32X3, M, N, K, taps)
+    report(f"f32x3_wgrad_workspace/M{M}N{N}K{K}t{taps}{'/big' if big else ''}", workspace_bytes=need)
+    if need > 0:
+        prev = ops.set_f32_matmul("x3")
+        try:
+            g1 = ops.gemm_tn(dy, a, **kw)
+            g2 = ops.gemm_tn(dy, a, **kw)
+        finally:
+            ops.set_f32_matmul(prev)
+        assert torch.equal(g1, g2) and torch.equal(g1, errs["x3"][1])
 
 
 def test_f32x3_mode_unet_vs_golden(golden_dir):

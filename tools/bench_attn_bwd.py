@@ -1,6 +1,8 @@
 """Fused attention backward, per-variant timing at the UNet's shapes (B=32, H=16, D=64): the 256-key sweep, the 512-key sweep and
 the 512-key sweep without its atomics (timing only).   python tools/bench_attn_bwd.py [N ...]"""
+import os
 import sys
+os.environ["OSUF_ALLOW_TIMING_BUILDS"] = "1"        # the no-atomics timing build is refused without it
 sys.path.insert(0, "/root/repo")
 import torch
 from osufusion_amd import ops

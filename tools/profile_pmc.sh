@@ -11,7 +11,7 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "mfma SQ_VALU_MFMA_BUSY_CYCLES
   name=$1; shift
   out="$ROOT/gpurun_out/pmc_${TAG}_$name"
   mkdir -p "$out"
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out" -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-sampler > "$out/bench.json" 2> "$out/bench.err" || { tail -5 "$out/bench.err"; exit 1; }
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out" -- python3 "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-sampler --no-config5 > "$out/bench.json" 2> "$out/bench.err" || { tail -5 "$out/bench.err"; exit 1; }
   f=$(find "$out" -name "*counter_collection.csv" | head -1)
   # keep only the attention / GEMM kernels' rows: the full file has one row per dispatch and counter
   (head -1 "$f"; grep -E "mqa_|gemm_" "$f") > "$ROOT/gpurun_out/${TAG}_${name}_counter_collection.csv"
