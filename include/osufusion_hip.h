@@ -37,6 +37,8 @@ extern "C" {
 #define OSUF_DQ_SLABS 1
 #define OSUF_DQ_ATOMIC_256 2      /* force the 8-wave, 256-key sweep */
 #define OSUF_DQ_ATOMIC_512 3      /* force the 4-wave, 512-key sweep (whole 512-key blocks: N % 512 == 0, else OSUF_EUNSUPPORTED) */
+#define OSUF_DQ_ATOMIC_512A 5     /* the 512-key sweep with its hand-placed loop (tools/gen_attn_bwd512.py): dK / dV bit-identical to
+                                     OSUF_DQ_ATOMIC_512; whole 512-key blocks and an even number of (head, query block) pairs per part */
 #define OSUF_DQ_TIMING_512 4      /* DEBUG: the 512-key sweep WITHOUT its atomics (prices the loop; dq comes back zero) -- refused with
                                      OSUF_EUNSUPPORTED unless the process environment holds OSUF_ALLOW_TIMING_BUILDS=1 */
 

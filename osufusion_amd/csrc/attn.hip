@@ -1418,6 +1418,151 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512_kernel(AttnArgs a, fl
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Fused backward, 512 keys per workgroup, HAND-PLACED LOOP (round 4): the algorithm, LDS images, fragment maps and accumulation orders of
+// mqa_bwd_fused512_kernel above (dK / dV are bit-identical to it), with the loop between the prologue and the epilogue emitted by
+// tools/gen_attn_bwd512.py as one asm statement on fixed physical registers (attn_bwd512_asm.inc; the register map is at the top of the
+// generator): 538 instead of 764 non-MFMA instructions per (head, 32-query block) pair, LDS-DMA stages, tile-pipelined matrix order.
+// Here: everything that is per-lane arithmetic once per workgroup (the loop's lane offsets, the resident K image, the V fragments, stage 0).
+// Whole 512-key blocks only (N % 512 == 0), hence niter = (N / 32 / qsplit) * H is even: the loop is unrolled by two.
+// ------------------------------------------------------------------------------------------------------
+#include "attn_bwd512_asm.inc"
+typedef __attribute__((ext_vector_type(32))) uint32_t u32x32;
+typedef __attribute__((ext_vector_type(8))) uint32_t u32x8;
+typedef __attribute__((ext_vector_type(32))) float f32x32;
+__global__ __launch_bounds__(256, 1) void mqa_bwd_fused512a_kernel(AttnArgs a, float* dq32) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][Q 4K | dO 4K | -lse/c 128 | -delta 128] | K image 64K | [2] dS image 32K
+  constexpr int kStage = 4096 + 4096 + 256;
+  char* kimg = smem + 2 * kStage;
+  char* eimg = kimg + 65536;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int nkb = a.N / 512;
+  const int per_split = (int)gridDim.x / a.qsplit;
+  const int part = (int)blockIdx.x / per_split, bid = (int)blockIdx.x - part * per_split;
+  const int xcd = bid & 7, qid = bid >> 3;
+  const int b = (qid / nkb) * 8 + xcd;
+  const int kb = qid % nkb;
+  if (b >= a.B) return;
+  const float c = a.scale * kLog2e;
+  const int nqb = a.N >> 5;
+  const int qb_per = nqb / a.qsplit;
+  const int qb_begin = part * qb_per;
+  const int niter = qb_per * a.H;                                  // even (host-checked)
+  const int key0 = kb * 512 + wave * 128;
+
+  // V fragments -> registers (v0..v63 of the loop), K rows -> the resident image
+  u32x32 vf0, vf1;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const long m = (long)b * a.N + key0 + t * 32 + lr;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const u32x4 z = *reinterpret_cast<const u32x4*>(a.k + m * a.ldk + 16 * ks + 8 * lh);
+      const u32x4 z2 = *reinterpret_cast<const u32x4*>(a.v + m * a.ldv + 16 * ks + 8 * lh);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { if (t < 2) vf0[16 * t + 4 * ks + j] = z2[j]; else vf1[16 * (t - 2) + 4 * ks + j] = z2[j]; }
+      *reinterpret_cast<u32x4*>(kimg + tile_off(wave * 128 + t * 32 + lr, (2 * ks + lh) * 16)) = z;
+    }
+  }
+  // stage 0 = the first pair, as mqa_bwd_fused512_kernel stages it; the previous pair's dS image (slot 1) = zeros: the first iteration adds 0.0
+  {
+    const int lrow = tid >> 3, lchunk = tid & 7;
+    const long row0 = (long)b * a.N + qb_begin * 32;
+    *reinterpret_cast<u32x4*>(smem + tile_off(lrow, lchunk * 16)) = *reinterpret_cast<const u32x4*>(a.q + (row0 + lrow) * a.ldq + lchunk * 8);
+    *reinterpret_cast<u32x4*>(smem + 4096 + tile_off(lrow, lchunk * 16)) = *reinterpret_cast<const u32x4*>(a.dout + (row0 + lrow) * a.lddo + lchunk * 8);
+    if (tid < 64) {
+      const float* src = (tid & 32) ? a.delta : a.lse2;
+      reinterpret_cast<float*>(smem + 8192)[tid] = src[(long)b * a.H * a.N + qb_begin * 32 + (tid & 31)] * ((tid & 32) ? -1.f : -1.f / c);
+    }
+    for (int i = tid; i < 32768 / 16; i += 256) reinterpret_cast<u32x4*>(eimg + 32768)[i] = u32x4{0u, 0u, 0u, 0u};
+  }
+  // the loop's lane offsets (LDS byte addresses; immediates carry slot, tile and k-step)
+  const uint32_t sb = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
+  const int g4 = lane >> 4, ip = lane & 15, tq = ip >> 2, tp = ip & 3, cb = ((lane >> 4) & 1) * 16;
+  u32x32 adr;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) adr[i] = 0u;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    adr[ks] = sb + tile_off(lr, (2 * ks + lh) * 16);                                       // RS: row fragments of a stage tile
+    adr[4 + ks] = sb + 2 * kStage + wave * 16384 + tile_off(lr, (2 * ks + lh) * 16);       // RK: row fragments of this wave's K rows
+  }
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int var = 0; var < 2; ++var) adr[8 + 2 * dt + var] = sb + tile_off(8 * var + 4 * lh + tq, (dt * 32 + cb + 4 * tp) * 2) - 8 * var * 128;   // T (LaneOffs::tr)
+  adr[12] = sb + 2 * kStage + tile_off(8 * g4 + tq, (wave * 16 + 4 * tp) * 2);            // KO: K columns of the dQ tiles
+  adr[13] = sb + 2 * kStage + tile_off(8 * g4 + 4 + tq, (wave * 16 + 4 * tp) * 2);
+#pragma unroll
+  for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) adr[14 + 2 * qh + j] = sb + 2 * kStage + 65536 + ds_img_off512(8 * g4 + tq + 4 * j, 4 * qh + tp);                    // EO: dS image, transposed
+#pragma unroll
+  for (int g = 0; g < 4; ++g) adr[18 + g] = sb + 2 * kStage + 65536 + ds_img_off512(wave * 128 + lr, 2 * g + lh);                                    // EW: dS rows of this lane's key
+  adr[22] = sb + 8192 + 16 * lh;                                                            // CR: row constants (b128 reads)
+  adr[23] = sb + 8192 + lane * 4;                                                           // CW: ... written (every wave the same 256 bytes)
+  {
+    const int row = 8 * wave + (lane >> 3), x = (row >> 1) & 7, f = ((x & 1) << 2) | (x >> 1), chunk = (lane & 7) ^ f;   // source-side swizzle of tile_off
+    adr[24] = (uint32_t)(row * (int)a.ldq + chunk * 8) * 2u;                                // QOFF / DOOFF: byte offsets of this lane's 16 B of the DMA piece
+    adr[25] = (uint32_t)(row * (int)a.lddo + chunk * 8) * 2u;
+  }
+  adr[26] = (uint32_t)(lane & 31) * 4u;                                                     // COFF
+  u32x32 aox;                                                                               // v192..v223; AO = v212..v219: byte offsets of the 8 atomics
+#pragma unroll
+  for (int i = 0; i < 32; ++i) aox[i] = 0u;
+  {
+    const uint32_t rowb = (uint32_t)(a.H * D) * 4u;
+    const uint32_t aoffb = (uint32_t)((4 * g4) * (a.H * D) + wave * 16 + ip) * 4u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) aox[20 + i] = aoffb + (uint32_t)(16 * (i >> 2) + (i & 3)) * rowb;
+  }
+  // loop state: pointers of the SECOND pair (the first is staged above), dQ rows of the first
+  const int h1 = a.H > 1 ? 1 : 0, qb1 = qb_begin + (a.H > 1 ? 0 : 1);
+  const long hn = (long)b * a.H * a.N;
+  auto uni = [](uint64_t x) {                                                               // block-uniform by construction; tell hipcc (physical SGPR operands)
+    return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(x >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)x);
+  };
+  uint64_t pq = uni((uint64_t)(a.q + ((long)b * a.N + qb1 * 32) * a.ldq + h1 * D));
+  uint64_t pdo = uni((uint64_t)(a.dout + ((long)b * a.N + qb1 * 32) * a.lddo + h1 * D));
+  uint64_t pls = uni((uint64_t)(a.lse2 + hn + (long)h1 * a.N + qb1 * 32));
+  uint64_t pdl = uni((uint64_t)(a.delta + hn + (long)h1 * a.N + qb1 * 32));
+  uint64_t pdq = uni((uint64_t)(dq32 + ((long)b * a.N + qb_begin * 32) * (a.H * D)));
+  const uint64_t wq = uni((uint64_t)((32 * a.ldq - (long)(a.H - 1) * D) * 2)), wdo = uni((uint64_t)((32 * a.lddo - (long)(a.H - 1) * D) * 2));
+  const uint64_t wls = uni((uint64_t)((32 - (long)(a.H - 1) * a.N) * 4)), wdq = uni((uint64_t)((32L * a.H * D - (long)(a.H - 1) * D) * 4));
+  uint32_t cnt = __builtin_amdgcn_readfirstlane((uint32_t)(niter / 2));
+  const uint32_t hh = __builtin_amdgcn_readfirstlane((uint32_t)a.H), n4 = __builtin_amdgcn_readfirstlane((uint32_t)a.N * 4u);
+  // (floats come out of VALU instructions, and hipcc folds __builtin_amdgcn_readfirstlane of a value it knows to be uniform: an opaque one)
+  auto rfl = [](float x) { uint32_t r; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(r) : "v"(x)); return r; };
+  const uint32_t cbits = rfl(c), nrc = rfl(-1.f / c);
+  const uint32_t m0base = __builtin_amdgcn_readfirstlane(sb + (uint32_t)wave * 1024u);
+  __syncthreads();
+  f32x32 acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7;                                    // dK^T tiles 0..3, dV^T tiles 0..3 (the loop's a[0:255], copied to v[0:255] at its end)
+  asm volatile(OSUF_BWD512A_ASM
+               : "={v[0:31]}"(acc0), "={v[32:63]}"(acc1), "={v[64:95]}"(acc2), "={v[96:127]}"(acc3), "={v[128:159]}"(acc4), "={v[160:191]}"(acc5),
+                 "={v[192:223]}"(acc6), "={v[224:255]}"(acc7), "+{s[48:49]}"(pq), "+{s[50:51]}"(pdo), "+{s[52:53]}"(pls), "+{s[54:55]}"(pdl),
+                 "+{s[56:57]}"(pdq), "+{s60}"(cnt)
+               : "{v[0:31]}"(vf0), "{v[32:63]}"(vf1), "{v[224:255]}"(adr), "{v[192:223]}"(aox), "{s61}"(hh), "{s65}"(n4), "{s[66:67]}"(wq),
+                 "{s[68:69]}"(wdo), "{s[70:71]}"(wls), "{s[72:73]}"(wdq), "{s74}"(cbits), "{s75}"(nrc), "{s76}"(m0base)
+               : OSUF_BWD512A_CLOBBERS);
+  const f32x32 dkv[8] = {acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int key = key0 + t * 32 + lr;
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] = dkv[t][r]; dk[1][r] = dkv[t][16 + r]; dv[0][r] = dkv[4 + t][r]; dv[1][r] = dkv[4 + t][16 + r]; }
+    if (a.qsplit > 1) {
+      const long prow = ((long)part * a.B + b) * a.N + key;
+      store_grad_row(a.wsk + prow * D, dk, 1.f, nullptr, nullptr, lh);
+      store_grad_row(a.wsv + prow * D, dv, 1.f, nullptr, nullptr, lh);
+    } else {
+      store_grad(a.dk, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dk, a.scale, a.rcos, a.rsin, key, lh);
+      store_grad(a.dv, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dv, 1.f, nullptr, nullptr, key, lh);
+    }
+  }
+}
+
 // finishing pass of the fused backward's dQ: fp32 sums [M][H*64] -> scale, RoPE transpose (as store_grad_row), cast, into dq [M][lddq]
 template <typename TO>
 __global__ __launch_bounds__(256) void dq_finish_kernel(const float* __restrict__ dq32, TO* dq, long lddq, long M, int N, int H, float scale,
@@ -1793,7 +1938,7 @@ static long fused_dq_bytes(int B, int H, int N, int out_dtype, int dq_mode) {
 // Which sweep an atomic-dQ call runs, and in how many query parts.  512 keys per workgroup (mqa_bwd_fused512_kernel) halves the dQ
 // atomic bytes but gives half as many workgroups: it is taken where whole 32-query blocks and enough work per part remain.
 static bool fused_use512(int B, int N, int dq_mode) {
-  if (dq_mode == OSUF_DQ_ATOMIC_512 || dq_mode == OSUF_DQ_TIMING_512) return true;
+  if (dq_mode == OSUF_DQ_ATOMIC_512 || dq_mode == OSUF_DQ_TIMING_512 || dq_mode == OSUF_DQ_ATOMIC_512A) return true;
   if (dq_mode != OSUF_DQ_ATOMIC) return false;
   // whole 512-key blocks only: a padded key's K / V rows are zero, but its S accumulator starts at -lse2 / c, so p = exp2(-lse2) and
   // dS = p * (-delta) are not -- for a row with lse2 < -128 p overflows and inf x 0 lands in dQ as NaN
@@ -1808,7 +1953,14 @@ static int fused512_qsplit(int B, int N, int forced) {
   while (sp < 8 && blocks * sp < 256 && (N / 32) / (sp * 2) >= 8) sp *= 2;
   return sp;
 }
-static bool fused_mode_ok(int dq_mode) { return dq_mode >= OSUF_DQ_ATOMIC && dq_mode <= OSUF_DQ_TIMING_512; }
+static bool fused_mode_ok(int dq_mode) { return dq_mode >= OSUF_DQ_ATOMIC && dq_mode <= OSUF_DQ_ATOMIC_512A; }
+// the hand-placed loop (mqa_bwd_fused512a_kernel) walks the pairs two at a time and carries 32-bit byte offsets: whole query parts of an even
+// number of pairs, rows of at most 2^31 bytes per sample
+static bool fused512a_ok(const AttnArgs& a, int N) {
+  const int nqb = N / 32;
+  return (N % 512) == 0 && a.qsplit >= 1 && nqb % a.qsplit == 0 && (((nqb / a.qsplit) * a.H) % 2) == 0 &&
+         (long)N * a.ldq * 2 < (1L << 31) && (long)N * a.lddo * 2 < (1L << 31) && (long)a.H * D * 4 * 20 < (1L << 31);
+}
 static long fused_dkv_ws_bytes(int B, int N, int qsplit, int dq_mode) {
   if (!fused_use512(B, N, dq_mode)) return osuf_mqa_bwd_dkv_workspace_bytes(B, N, qsplit);
   const int sp = fused512_qsplit(B, N, qsplit);
@@ -1846,7 +1998,16 @@ extern "C" int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long l
     hipError_t e = hipMemsetAsync(dq32, 0, (size_t)dq_bytes, stream);
     if (e != hipSuccess) return (int)e;
   }
-  if (use512) {
+  if (use512 && dq_mode == OSUF_DQ_ATOMIC_512A) {
+    if (!fused512a_ok(a, N)) return OSUF_EUNSUPPORTED;
+    const int lds = 2 * (4096 + 4096 + 256) + 65536 + 2 * 32768;
+    static bool attr512a = false;
+    if (!attr512a) {
+      (void)hipFuncSetAttribute((const void*)mqa_bwd_fused512a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr512a = true;
+    }
+    hipLaunchKernelGGL(mqa_bwd_fused512a_kernel, dim3((N / 512) * b8 * a.qsplit), dim3(256), lds, stream, a, dq32);
+  } else if (use512) {
     const int lds = 2 * (4096 + 4096 + 256) + 65536 + 2 * 32768;
     void (*kern)(AttnArgs, float*) = dq_mode == OSUF_DQ_TIMING_512 ? mqa_bwd_fused512_kernel<false> : mqa_bwd_fused512_kernel<true>;
     static bool attr512[2] = {false, false};

@@ -19,7 +19,7 @@ def _stale() -> bool:
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    deps = [HERE / s for s in SOURCES] + [HERE / "common.hpp", HERE / "attn_generic.hpp", Path(__file__)]
+    deps = [HERE / s for s in SOURCES] + [HERE / "common.hpp", HERE / "attn_generic.hpp", HERE / "attn_bwd512_asm.inc", Path(__file__)]
     return any(d.stat().st_mtime > t for d in deps)
 
 

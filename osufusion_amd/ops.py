@@ -446,7 +446,8 @@ def mqa_fwd_masked(qkv: torch.Tensor, mask4: torch.Tensor, B: int, N: int, H: in
 
 ATTN_AUTO, ATTN_PLAIN, ATTN_PIPE, ATTN_FUSED, ATTN_FUSED_SLABS = 0, 1, 2, 3, 4
 ATTN_FUSED256, ATTN_FUSED512, ATTN_FUSED512_TIMING = 5, 6, 7     # force the 256- / 512-key sweep of ATTN_FUSED; 512 without atomics (timing only)
-_FUSED_DQ_MODE = {ATTN_FUSED: 0, ATTN_FUSED_SLABS: 1, ATTN_FUSED256: 2, ATTN_FUSED512: 3, ATTN_FUSED512_TIMING: 4}      # OSUF_DQ_*
+ATTN_FUSED512A = 8                                               # the 512-key sweep with the generated, hand-placed loop
+_FUSED_DQ_MODE = {ATTN_FUSED: 0, ATTN_FUSED_SLABS: 1, ATTN_FUSED256: 2, ATTN_FUSED512: 3, ATTN_FUSED512_TIMING: 4, ATTN_FUSED512A: 5}      # OSUF_DQ_*
 # What AttentionFn.backward asks for: ATTN_FUSED = one key-stationary sweep, dQ by fp32 atomics (fastest at every UNet shape, measured
 # round 2); ATTN_FUSED_SLABS = the same sweep with a fixed-order dQ sum (bit-reproducible); ATTN_AUTO = the dQ + dK/dV kernel pair.
 ATTN_BWD_DEFAULT = ATTN_FUSED
