@@ -1521,7 +1521,8 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512a_kernel(AttnArgs a, f
   const int h1 = a.H > 1 ? 1 : 0, qb1 = qb_begin + (a.H > 1 ? 0 : 1);
   const long hn = (long)b * a.H * a.N;
   auto uni = [](uint64_t x) {                                                               // block-uniform by construction; tell hipcc (physical SGPR operands)
-    return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(x >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)x);
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32) |      // (the builtin returns int: widen it unsigned)
+           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
   };
   uint64_t pq = uni((uint64_t)(a.q + ((long)b * a.N + qb1 * 32) * a.ldq + h1 * D));
   uint64_t pdo = uni((uint64_t)(a.dout + ((long)b * a.N + qb1 * 32) * a.lddo + h1 * D));
