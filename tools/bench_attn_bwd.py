@@ -24,7 +24,7 @@ for N in ([int(a) for a in sys.argv[1:]] or [4096, 2048, 1024, 512]):
     ops.call("osuf_attn_delta", do.data_ptr(), H * D, o.data_ptr(), H * D, 1, delta.data_ptr(), B, H, N, D, st)
     f = 8.0 * B * H * N * N * D
     row = []
-    for name, var in (("fused256", ops.ATTN_FUSED256), ("fused512", ops.ATTN_FUSED512), ("fused512-noatomics", ops.ATTN_FUSED512_TIMING)):
+    for name, var in (("fused256", ops.ATTN_FUSED256), ("fused512", ops.ATTN_FUSED512), ("fused512a", ops.ATTN_FUSED512A), ("fused512-noatomics", ops.ATTN_FUSED512_TIMING)):
         t = timeit(lambda: ops.mqa_bwd(qkv, o, do, lse, B, N, H, D, D ** -0.5, torch.bfloat16, None, None, variant=var, delta=delta))
         row.append(f"{name} {t:7.3f} ms ({f / t / 1e9:5.0f} alg TF/s)")
     print(f"N={N:5d}  " + " | ".join(row), flush=True)

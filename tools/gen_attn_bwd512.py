@@ -26,6 +26,13 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 OUT = ROOT / "osufusion_amd" / "csrc" / "attn_bwd512_asm.inc"
+# timing-only triage builds (wrong results, never shipped): --drop valu,atomics,dq,lds,barrier,dma  --out <file>
+DROP = set()
+for i, a in enumerate(sys.argv):
+    if a == "--drop":
+        DROP = set(sys.argv[i + 1].split(","))
+    if a == "--out":
+        OUT = Path(sys.argv[i + 1])
 
 # ---- register map (arch VGPRs) -----------------------------------------------------------------------------------------------
 VF, QA, DA, TRD, TRQ, S, DP, PF, DF, KF = 0, 64, 80, 96, 112, 128, 144, 160, 168, 176
@@ -74,6 +81,23 @@ class Emitter:
         self.valu_ws = {}        # reg -> ws of the last VALU write
         self.count = {}
         self.nops = 0
+        # symbolic dataflow (which value sits in which register), compared between the hand-ordered body and the list-scheduled one
+        self.val = {}            # reg -> value id
+        self.sinks = []          # LDS stores / atomics: (kind, ids ...)
+        self.epoch = 0           # barriers passed (LDS contents differ between iterations)
+        self.pepoch = [0, 0]     # advances of the stage pointers / of the dQ pointers so far
+
+    def vid(self, r):
+        return self.val.get(r, ("init", r))
+
+    def define(self, op, dsts, srcs, extra=()):
+        import hashlib
+        key = repr((op, tuple(self.vid(r) for r in sorted(srcs)), extra))
+        for j, r in enumerate(sorted(dsts)):
+            self.val[r] = hashlib.md5((key + str(j)).encode()).hexdigest()[:16]
+
+    def sink(self, kind, srcs, extra=()):
+        self.sinks.append((kind, tuple(self.vid(r) for r in sorted(srcs)), extra))
 
     # -- low level
     def raw(self, text, kind):
@@ -122,34 +146,55 @@ class Emitter:
 
     # -- instruction classes
     def valu(self, text, reads, writes, kind="valu"):
+        if "valu" in DROP:
+            return
         self._wait_regs(reads | writes)
         self._mfma_result_hazard(reads | writes)
         self.raw(text, kind)
+        self.define(text.split()[0] + "|" + "|".join(t for t in text.replace(",", " ").split()[1:] if not t.startswith("v")), writes, reads)
         for r in writes:
             self.valu_ws[r] = self.ws
 
     def salu(self, text, cond=False):
         """cond: inside a scalar branch that may be skipped -- counts as no wait state for the hazard clock"""
+        if "barrier" in DROP and text == "s_barrier":
+            return
         self.raw(text, "salu")
+        if text == "s_barrier":
+            self.epoch += 1
         if cond:
             self.ws -= 1
 
     def ds_read(self, text, addr, writes, kind):
+        if "lds" in DROP:
+            return
         self._wait_regs(writes)              # (a register with a load still in flight is never re-targeted; this documents it)
         self._mfma_result_hazard(writes)
         self.raw(text, kind)
+        # (the K image is written once, before the loop: its reads mean the same in every iteration)
+        self.define(kind + "|" + text.split("offset:")[1], writes, vset(addr), () if addr in (RK, RK + 1, RK + 2, RK + 3, KO, KO + 1) else (self.epoch,))
         self.lds.append(set(writes))
 
     def ds_write(self, text, reads, kind="ds_write"):
+        if "lds" in DROP:
+            return
         self._wait_regs(reads)
         self._mfma_result_hazard(reads)
         self.raw(text, kind)
+        self.sink(text.split()[0] + "|" + text.split("offset:")[1], reads, (self.epoch,))
         self.lds.append(set())
 
     def vmem(self, text, reads, writes, kind):
+        if (kind == "atomic" and "atomics" in DROP) or (kind in ("dma", "gload") and "dma" in DROP):
+            return
         self._wait_regs(reads | writes)
         self._mfma_result_hazard(reads | writes)
         self.raw(text, kind)
+        sbase = text.split("s[")[1].split("]")[0]
+        if writes:
+            self.define(kind + "|" + sbase, writes, reads, (self.epoch, tuple(self.pepoch)))
+        else:
+            self.sink(kind + "|" + sbase, reads, (self.epoch, tuple(self.pepoch), self.lines[-3] if kind == "dma" else ""))
         self.vm.append(set(writes))
 
     def mfma(self, big, dst, a, b, c, text):
@@ -166,6 +211,12 @@ class Emitter:
         if self.ws - t < self.VALU_TO_MFMA_WS:
             self.nop(self.VALU_TO_MFMA_WS - (self.ws - t))
         self.raw(text, "mfma32" if big else "mfma16")
+        # (A and B fragments are register quadruples at distinct bases: tag each source with its role)
+        import hashlib
+        key = repr(("mfma", big, tuple(self.vid(r) for r in sorted(a)), tuple(self.vid(r) for r in sorted(b))))
+        for j, r in enumerate(sorted(dst)):
+            cj = self.vid(r) if c else 0
+            self.val[r] = hashlib.md5((key + repr(cj) + str(j)).encode()).hexdigest()[:16]
         for r in dst:
             self.mfma_ready[r] = self.ws + (self.MFMA32_WS if big else self.MFMA16_WS)
             self.mfma_chain[r] = big
@@ -199,6 +250,8 @@ def tr_frag(e, dst, tile_imm, s2, dt):
 
 def dq_reads(e, er, ks):
     """operands of dQ k-step ks (keys 32 ks .. 32 ks + 31 of the previous pair's dS image, this wave's 16 head-dim columns of K)"""
+    if "dq" in DROP:
+        return
     e.rdtr(DQB, KO, ks * 4096)
     e.rdtr(DQB + 2, KO + 1, ks * 4096)
     e.rdtr(DQA0, EO, er + ks * 2048)
@@ -208,6 +261,8 @@ def dq_reads(e, er, ks):
 
 
 def dq_mma(e, first):
+    if "dq" in DROP:
+        return
     e.mfma16(ACC0, DQA0, DQB, first)
     e.mfma16(ACC1, DQA1, DQB, first)
 
@@ -264,6 +319,7 @@ def merge(*gaplists):
 
 def advance_stage_pointers(e, tag):
     """stage pointers -> the pair after the one just requested (clamped at the last pair)"""
+    e.pepoch[0] += 1
     L = f"{tag}"
     e.salu(f"s_cmp_eq_u32 s{SREM}, 0", cond=True)
     e.salu(f"s_cbranch_scc1 .Lsd{L}%=", cond=True)
@@ -285,6 +341,7 @@ def advance_stage_pointers(e, tag):
 
 def advance_dq_pointers(e, tag):
     L = f"{tag}"
+    e.pepoch[1] += 1
     e.salu(f"s_mov_b64 s[{SDQP}:{SDQP + 1}], s[{SDQC}:{SDQC + 1}]")
     e.salu(f"s_add_u32 s{SHD}, s{SHD}, 1", cond=True)
     e.salu(f"s_cmp_eq_u32 s{SHD}, s{SH}", cond=True)
@@ -415,6 +472,215 @@ def body(e, sg, tag):
     e.salu("s_barrier")
 
 
+class Item:
+    __slots__ = ("name", "fn", "cost", "after", "before", "deps", "order", "cls")
+
+    def __init__(self, name, fn, cost, cls, after=-1, before=10 ** 6, deps=()):
+        self.name, self.fn, self.cost, self.cls, self.after, self.before, self.deps = name, fn, cost, cls, after, before, tuple(deps)
+
+
+# issue-cost model of the placement (cycles): an MFMA holds the wave's issue for 8 of its 32 (16x16x32: 8 of 16) cycles, so a gap hides
+# 24 (8) cycles of other instructions (MI355X_MICROARCH.md, "Per-instruction cycle constants"); LDS instructions measured at ~4.8 (SQ counters).
+# The four waves of a workgroup run this one stream in near lock-step (one barrier per pair), so a burst of LDS instructions in the stream is a
+# 4-wave burst at the one LDS: SQ_WAIT_INST_LDS was 14 % of the wave cycles with six-read bursts -> at most LDS_CAP LDS instructions per gap.
+C_V, C_EXP, C_L, C_W = 4, 8, 5, 6
+BUDGET_BIG, BUDGET_SMALL = 30, 10
+LDS_CAP_BIG, LDS_CAP_SMALL = 3, 1
+LAT = 3                                                           # an LDS read sits at least this many slots ahead of its consumer
+GAPLOG = []
+
+
+def body_sched(e, sg, tag):
+    """One iteration (pair parity sg) as a spine of matrix instructions with every other instruction assigned to a gap by a list scheduler:
+    earliest / latest gap and producer items per instruction, filled towards ~30 (10) cycles of issue per 32x32x16 (16x16x32) gap."""
+    st, stw = sg * STAGE, (1 - sg) * STAGE
+    ew, er = sg * 32768, (1 - sg) * 32768
+    slots = []                                                    # (name, emit function, gap budget)
+
+    def big(name, fn):
+        slots.append((name, fn, BUDGET_BIG))
+
+    def kstep(j):
+        slots.append((f"Q{j}a", lambda: None if "dq" in DROP else e.mfma16(ACC0, DQA0, DQB, j == 0), BUDGET_SMALL))
+        slots.append((f"Q{j}b", lambda: None if "dq" in DROP else e.mfma16(ACC1, DQA1, DQB, j == 0), BUDGET_SMALL))
+
+    def group_s(t):
+        for ks in range(4):
+            big(f"S{t}.{ks}", lambda ks=ks: e.mfma32(S, QA + 4 * ks, KF + 4 * ks))
+
+    def group_p(t):
+        for ks in range(4):
+            big(f"P{t}.{ks}", lambda ks=ks: e.mfma32(DP, DA + 4 * ks, VF + 16 * t + 4 * ks))
+
+    def group_v(t):
+        for i in range(4):
+            s2, dt = i >> 1, i & 1
+            big(f"V{t}.{i}", lambda s2=s2, dt=dt: e.mfma32(DV(t, dt), TRD + 8 * s2 + 4 * dt, PF + 4 * s2, agpr=True))
+
+    def group_k(t):
+        for i in range(4):
+            s2, dt = i >> 1, i & 1
+            big(f"K{t}.{i}", lambda s2=s2, dt=dt: e.mfma32(DK(t, dt), TRQ + 8 * s2 + 4 * dt, DF + 4 * s2, agpr=True))
+
+    big("K3c", lambda: dk3_mfma(2)(e))
+    big("K3d", lambda: dk3_mfma(3)(e))
+    kstep(0)
+    group_s(0); kstep(1)
+    group_p(0); kstep(2)
+    j = 3
+    for t in range(4):
+        group_v(t); kstep(j); j += 1
+        if t < 3:
+            group_s(t + 1); kstep(j); j += 1
+            group_k(t); kstep(j); j += 1
+            group_p(t + 1); kstep(j); j += 1
+    assert j == 16
+    big("K3a", lambda: dk3_mfma(0)(e))
+    big("K3b", lambda: dk3_mfma(1)(e))
+    idx = {n: i for i, (n, _, _) in enumerate(slots)}
+    items = []
+
+    def add(name, fn, cost, cls, after=-1, before=10 ** 6, deps=()):
+        items.append(Item(name, fn, cost, cls, after, before, deps))
+
+    def add_tr(name, dst, tile_imm, s2, dt, **kw):
+        """the two transposed reads of lds_tr_frag(tile, rowbase = 16 s2, dt)"""
+        add(name + "l", (lambda: e.rdtr(dst, T + 2 * dt, tile_imm + 2048 * s2)), C_L, "L", **kw)
+        add(name + "h", (lambda: e.rdtr(dst + 2, T + 2 * dt + 1, tile_imm + 2048 * s2 + 1024)), C_L, "L", **kw)
+
+    def add_dq(jq, after, before_a, before_b):
+        for i, (dst, adr, imm) in enumerate(((DQB, KO, jq * 4096), (DQA0, EO, er + jq * 2048), (DQA1, EO + 2, er + jq * 2048))):
+            for h in range(2):
+                add(f"dqr{jq}.{i}{h}", (lambda dst=dst, adr=adr, imm=imm, h=h: e.rdtr(dst + 2 * h, adr + h, imm)), C_L, "L",
+                    after=after[1] if i == 2 else after[0], before=before_b if i == 2 else before_a)
+
+    # ---- head: operands of the pair (after the barrier)
+    if "dq" not in DROP:
+        add_dq(0, (-1, -1), idx["Q0a"], idx["Q0b"])
+    for g in range(4):
+        add(f"cs0.{g}", (lambda g=g: const_s(e, st, g)), C_L, "L", before=idx["S0.0"] - LAT)
+    for ks in range(4):
+        add(f"qa.{ks}", (lambda ks=ks: e.rd128(QA + 4 * ks, RS + ks, st)), C_L, "L", before=idx[f"S0.{ks}"] - LAT)
+    for g in range(4):
+        add(f"cd0.{g}", (lambda g=g: const_dp(e, st, g)), C_L, "L", before=idx["P0.0"] - LAT)
+    for ks in range(4):
+        add(f"da.{ks}", (lambda ks=ks: e.rd128(DA + 4 * ks, RS + ks, st + 4096)), C_L, "L", before=idx[f"P0.{ks}"] - LAT)
+    for i in range(4):
+        s2, dt = i >> 1, i & 1
+        add_tr(f"trd.{i}", TRD + 8 * s2 + 4 * dt, st + 4096, s2, dt, before=idx[f"V0.{i}"] - LAT)
+        add_tr(f"trq.{i}", TRQ + 8 * s2 + 4 * dt, st, s2, dt, after=idx["K3d"], before=idx[f"K0.{i}"] - LAT)
+
+    def dma():
+        e.salu(f"s_add_u32 m0, s{SM0}, {stw}")
+        e.salu("s_nop 0")
+        e.vmem(f"global_load_lds_dwordx4 {vr(QOFF)}, s[{SQ}:{SQ + 1}]", vset(QOFF), set(), "dma")
+        e.salu(f"s_add_u32 m0, s{SM0}, {stw + 4096}")
+        e.salu("s_nop 0")
+        e.vmem(f"global_load_lds_dwordx4 {vr(DOOFF)}, s[{SDO}:{SDO + 1}]", vset(DOOFF), set(), "dma")
+        e.vmem(f"global_load_dword {vr(CL)}, {vr(COFF)}, s[{SLS}:{SLS + 1}]", vset(COFF), vset(CL), "gload")
+        e.vmem(f"global_load_dword {vr(CD)}, {vr(COFF)}, s[{SDL}:{SDL + 1}]", vset(COFF), vset(CD), "gload")
+    add("dma", dma, 36, "O", after=idx["S0.1"], before=idx["P0.2"])
+    add("adv", (lambda: advance_stage_pointers(e, tag)), 12, "O", deps=("dma",), before=idx["V0.2"])
+    # ---- per key tile
+    for t in range(4):
+        s_done, p_done = idx[f"S{t}.3"] + 3, idx[f"P{t}.3"] + 3     # first gap in which a VALU reader of the chain's result may sit (the emitter pads to 12 wait states)
+        vdead = lambda r: idx[f"V{t}.0"] if r < 8 else idx[f"V{t}.2"]
+        for jj in range(8):
+            add(f"mm{t}.{jj}", (lambda jj=jj: (mul_exp(e, 2 * jj), mul_exp(e, 2 * jj + 1))), 2 * C_V, "V", after=s_done, before=vdead(2 * jj))
+            add(f"ee{t}.{jj}", (lambda jj=jj: (exp(e, 2 * jj), exp(e, 2 * jj + 1))), 2 * C_EXP, "V", deps=(f"mm{t}.{jj}",), before=vdead(2 * jj))
+        for q in range(4):
+            add(f"pf{t}.{q}", (lambda q=q: (cvt(e, PF + 2 * q, S + 4 * q), cvt(e, PF + 2 * q + 1, S + 4 * q + 2))), 2 * C_V, "V",
+                deps=(f"ee{t}.{2 * q}", f"ee{t}.{2 * q + 1}"), before=vdead(4 * q))
+        kname = (lambda i: f"K{t}.{i}") if t < 3 else (lambda i: "K3a" if i == 0 else "K3b")
+        kdead = lambda g: idx[kname(0)] if g < 2 else (idx[kname(2)] if t < 3 else idx["K3b"])
+        for g in range(4):
+            for h in range(2):
+                add(f"dm{t}.{g}{h}", (lambda g=g, h=h: (ds_mul(e, 4 * g + 2 * h), ds_mul(e, 4 * g + 2 * h + 1))), 2 * C_V, "V", after=p_done,
+                    deps=(f"ee{t}.{2 * g + h}",), before=kdead(g))
+            dfd = [f"dm{t}.{g}0", f"dm{t}.{g}1"] + ([f"dw{t - 1}.{g}"] if t > 0 else [])
+            add(f"df{t}.{g}", (lambda g=g: [cvt(e, DF + 2 * g + q, DP + 4 * g + 2 * q) for q in range(2)]), 2 * C_V, "V", deps=dfd, before=kdead(g))
+            add(f"dw{t}.{g}", (lambda g=g, t=t: e.ds_write(f"ds_write_b64 {vr(EW + g)}, {vr(DF + 2 * g, 2)} offset:{ew + t * 2048}", vset(EW + g) | vset(DF + 2 * g, 2))),
+                C_W, "L", deps=(f"df{t}.{g}",))
+            if t < 3:
+                add(f"cs{t + 1}.{g}", (lambda g=g: const_s(e, st, g)), C_L, "L", deps=(f"dm{t}.{g}0", f"dm{t}.{g}1", f"pf{t}.{g}"), before=idx[f"S{t + 1}.0"] - LAT)
+                add(f"cd{t + 1}.{g}", (lambda g=g: const_dp(e, st, g)), C_L, "L", deps=(f"df{t}.{g}",), before=idx[f"P{t + 1}.0"] - LAT)
+        for ks in range(4):                                       # K rows of the next tile (of tile 0 again for the next pair: the image is resident)
+            tn = (t + 1) & 3
+            add(f"kf{t + 1}.{ks}", (lambda ks=ks, tn=tn: e.rd128(KF + 4 * ks, RK + ks, tn * 4096)), C_L, "L", after=idx[f"S{t}.{ks}"],
+                before=(idx[f"S{t + 1}.{ks}"] - LAT) if t < 3 else 10 ** 6)
+    # ---- dQ k-steps 1..15: operands are re-read into the same registers right behind the MFMAs that consumed them
+    if "dq" not in DROP:
+        for jq in range(1, 16):
+            add_dq(jq, (idx[f"Q{jq - 1}b"], idx[f"Q{jq - 1}b"]), idx[f"Q{jq}a"] - 1, idx[f"Q{jq}a"] - 1)
+    # ---- end of the iteration
+
+    def cw():
+        e.wait(vm=0)                                                                            # the row constants requested at the head (and with them
+        e.valu(f"v_mul_f32_e32 {vr(TMP0)}, s{SNRC}, {vr(CL)}", vset(CL), vset(TMP0))            #  every older operation: last iteration's atomics)
+        e.valu(f"v_mul_f32_e32 {vr(TMP1)}, -1.0, {vr(CD)}", vset(CD), vset(TMP1))
+        e.valu(f"v_cndmask_b32_e64 {vr(TMP0)}, {vr(TMP1)}, {vr(TMP0)}, s[{SMASK}:{SMASK + 1}]", vset(TMP0) | vset(TMP1), vset(TMP0))
+        e.ds_write(f"ds_write_b32 {vr(CW)}, {vr(TMP0)} offset:{stw}", vset(CW) | vset(TMP0), "ds_write")
+    add("cw", cw, 22, "O", after=idx["P3.2"], before=idx["K3a"])
+    for i in range(8):
+        acc = (ACC0 if i < 4 else ACC1) + (i & 3)
+        add(f"atom.{i}", (lambda i=i, acc=acc: e.vmem(f"global_atomic_add_f32 {vr(AO + i)}, {vr(acc)}, s[{SDQP}:{SDQP + 1}]", vset(AO + i) | vset(acc), set(), "atomic")),
+            5, "O", after=idx["K3a"], deps=("cw",))
+    add("advq", (lambda: advance_dq_pointers(e, tag)), 8, "O", deps=[f"atom.{i}" for i in range(8)])
+    for n, it in enumerate(items):
+        it.order = n
+    byname = {it.name: it for it in items}
+    for _ in range(6):                                            # a producer is due no later than its consumers
+        for it in reversed(items):
+            for d in it.deps:
+                byname[d].before = min(byname[d].before, it.before)
+
+    placed = set()
+    pending = list(items)
+
+    def fill(k, budget):
+        used, nlds, last = 0, 0, None
+        cap = LDS_CAP_BIG if budget == BUDGET_BIG else LDS_CAP_SMALL
+        while True:
+            cands = [it for it in pending if it.after <= k and all(d in placed for d in it.deps)]
+            if not cands:
+                break
+            cands.sort(key=lambda it: (it.before, it.order))
+            pick = None
+            if cands[0].before <= k + 1:
+                pick = cands[0]                                   # due now: placed whatever it costs
+            else:
+                fit = [c for c in cands if used + c.cost <= budget and not (c.cls == "L" and nlds >= cap)]
+                alt = [c for c in fit if c.cls != last]           # alternate LDS and vector instructions where the deadlines allow
+                if alt and alt[0].before <= fit[0].before + 12:
+                    pick = alt[0]
+                elif fit:
+                    pick = fit[0]
+            if pick is None:
+                break
+            pick.fn()
+            placed.add(pick.name)
+            pending.remove(pick)
+            used += pick.cost
+            nlds += pick.cls == "L"
+            last = pick.cls
+        return used
+
+    for k, (name, fn, budget) in enumerate(slots):
+        fn()
+        u = fill(k, budget)
+        GAPLOG.append((tag, name, budget, u))
+    while pending:                                                # (what has no deadline inside the iteration: the last dS rows)
+        ready = [it for it in pending if all(d in placed for d in it.deps)]
+        assert ready, [it.name for it in pending]
+        ready[0].fn(); placed.add(ready[0].name); pending.remove(ready[0])
+        GAPLOG.append((tag, "flush:" + ready[0].name, 0, ready[0].cost))
+    e.wait(lgkm=0)
+    e.salu("s_barrier")
+
+
+BODY = body if "--manual" in sys.argv else body_sched
+
+
 def generate():
     e = Emitter()
     # ---- prologue: accumulators, loop state
@@ -422,6 +688,8 @@ def generate():
         e.raw(f"v_accvgpr_write_b32 a{i}, 0", "init")
     for r in list(range(DF, DF + 8)) + list(range(TRQ, TRQ + 16)):                          # the head's dK MFMAs of a pair that does not exist: 0 x 0
         e.raw(f"v_mov_b32_e32 {vr(r)}, 0", "init")
+    for ks in range(4):                                                                     # K rows of tile 0 (each iteration re-reads them for the next pair)
+        e.rd128(KF + 4 * ks, RK + ks, 0)
     e.salu(f"s_mov_b64 s[{SDQP}:{SDQP + 1}], s[{SDQC}:{SDQC + 1}]")
     e.salu(f"s_mov_b32 s{SHD}, 0")
     e.salu(f"s_mov_b32 s{SHS}, 1")
@@ -438,13 +706,27 @@ def generate():
     def two_bodies(state):
         x = copy.deepcopy(state)
         x.lines, x.count, x.nops = [], {}, 0
-        body(x, 0, "a")
-        body(x, 1, "b")
+        BODY(x, 0, "a")
+        BODY(x, 1, "b")
         x.salu(f"s_sub_u32 s{SCNT}, s{SCNT}, 1")
         x.salu(f"s_cmp_lg_u32 s{SCNT}, 0")
         x.salu("s_cbranch_scc1 .Lloop%=")
         return x
 
+    # the list-scheduled body must compute, register by register and store by store, what the hand-ordered body computes (that one
+    # is pinned on the GPU: dK / dV bit-identical to the compiled kernel): same symbolic value in every register after two iterations,
+    # same set of LDS stores / atomics / DMA requests per iteration
+    if BODY is not body:
+        def trace(fn):
+            x = copy.deepcopy(e)
+            for tg in ("a", "b", "c", "d"):
+                fn(x, 0 if tg in "ac" else 1, tg)
+            return x
+        xm, xs = trace(body), trace(BODY)
+        # (not compared: KF -- the scheduled body leaves the NEXT pair's K rows there -- and the address / scratch registers from v192 up)
+        bad = [r for r in set(xm.val) | set(xs.val) if xm.vid(r) != xs.vid(r) and (r[0] == "a" or (r[1] < 192 and not KF <= r[1] < KF + 16))]
+        assert not bad, ("dataflow differs from the hand-ordered body in", sorted(bad)[:12])
+        assert sorted(map(repr, xm.sinks)) == sorted(map(repr, xs.sinks)), "stores / atomics differ from the hand-ordered body"
     first = two_bodies(e)
     second = two_bodies(first)
     third = two_bodies(second)
@@ -491,6 +773,14 @@ def main():
         tot = sum(v for k, v in per_pair.items() if not k.startswith("mfma"))
         print("per pair:", {k: per_pair[k] for k in sorted(per_pair)})
         print(f"non-MFMA instructions per pair: {tot:.0f}; s_nop wait states inserted in total: {e.nops}")
+    if "--gaps" in sys.argv:
+        seen = set()
+        for tag, name, budget, used in GAPLOG[-2 * 200:]:
+            if tag == "a" and (tag, name) not in seen:
+                seen.add((tag, name))
+                print(f"  {name:12s} budget {budget:3d} used {used:4d} {'#' * (used // 2)}")
+        tot = sum(max(32 if b == BUDGET_BIG else 16, 8 + u) for t, n, b, u in GAPLOG[-200:] if t == "a") 
+        print("issue-model cycles per iteration (sum over gaps of max(MFMA, 8 + fillers)):", tot)
     print("wrote", OUT, len(text), "lines")
 
 
