@@ -1477,62 +1477,62 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512a_kernel(AttnArgs a, f
     }
     for (int i = tid; i < 32768 / 16; i += 256) reinterpret_cast<u32x4*>(eimg + 32768)[i] = u32x4{0u, 0u, 0u, 0u};
   }
-  // the loop's lane offsets (LDS byte addresses; immediates carry slot, tile and k-step)
+  // the loop's lane offsets (LDS byte addresses; immediates carry slot, tile and k-step): v224..v255 of the loop, see tools/gen_attn_bwd512.py
   const uint32_t sb = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
   const int g4 = lane >> 4, ip = lane & 15, tq = ip >> 2, tp = ip & 3, cb = ((lane >> 4) & 1) * 16;
   u32x32 adr;
 #pragma unroll
   for (int i = 0; i < 32; ++i) adr[i] = 0u;
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    adr[ks] = sb + tile_off(lr, (2 * ks + lh) * 16);                                       // RS: row fragments of a stage tile
-    adr[4 + ks] = sb + 2 * kStage + wave * 16384 + tile_off(lr, (2 * ks + lh) * 16);       // RK: row fragments of this wave's K rows
+  {
+    const uint32_t rowb_ = (uint32_t)(a.H * D) * 4u;
+    const uint32_t aoffb = (uint32_t)((4 * g4) * (a.H * D) + wave * 16 + ip) * 4u;
+    adr[4] = aoffb;                                                                         // AO: byte offset of this lane's dQ element, query half 0 / 1 (rows: scalar bases)
+    adr[5] = aoffb + 16u * rowb_;
   }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) adr[8 + ks] = sb + 2 * kStage + wave * 16384 + tile_off(lr, (2 * ks + lh) * 16);   // RK: row fragments of this wave's K rows (stage tiles: less SKOF)
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int var = 0; var < 2; ++var) adr[8 + 2 * dt + var] = sb + tile_off(8 * var + 4 * lh + tq, (dt * 32 + cb + 4 * tp) * 2) - 8 * var * 128;   // T (LaneOffs::tr)
-  adr[12] = sb + 2 * kStage + tile_off(8 * g4 + tq, (wave * 16 + 4 * tp) * 2);            // KO: K columns of the dQ tiles
-  adr[13] = sb + 2 * kStage + tile_off(8 * g4 + 4 + tq, (wave * 16 + 4 * tp) * 2);
+    for (int var = 0; var < 2; ++var) adr[12 + 2 * dt + var] = sb + tile_off(8 * var + 4 * lh + tq, (dt * 32 + cb + 4 * tp) * 2) - 8 * var * 128;   // T (LaneOffs::tr)
+  adr[16] = sb + 2 * kStage + tile_off(8 * g4 + tq, (wave * 16 + 4 * tp) * 2);            // KO: K columns of the dQ tiles
+  adr[17] = sb + 2 * kStage + tile_off(8 * g4 + 4 + tq, (wave * 16 + 4 * tp) * 2);
 #pragma unroll
   for (int qh = 0; qh < 2; ++qh)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) adr[14 + 2 * qh + j] = sb + 2 * kStage + 65536 + ds_img_off512(8 * g4 + tq + 4 * j, 4 * qh + tp);                    // EO: dS image, transposed
+    for (int j = 0; j < 2; ++j) adr[18 + 2 * qh + j] = sb + 2 * kStage + 65536 + ds_img_off512(8 * g4 + tq + 4 * j, 4 * qh + tp);                    // EO: dS image, transposed
 #pragma unroll
-  for (int g = 0; g < 4; ++g) adr[18 + g] = sb + 2 * kStage + 65536 + ds_img_off512(wave * 128 + lr, 2 * g + lh);                                    // EW: dS rows of this lane's key
-  adr[22] = sb + 8192 + 16 * lh;                                                            // CR: row constants (b128 reads)
-  adr[23] = sb + 8192 + lane * 4;                                                           // CW: ... written (every wave the same 256 bytes)
+  for (int g = 0; g < 4; ++g) adr[22 + g] = sb + 2 * kStage + 65536 + ds_img_off512(wave * 128 + lr, 2 * g + lh);                                    // EW: dS rows of this lane's key
+  adr[26] = sb + 8192 + 16 * lh;                                                            // CR: row constants (b128 reads)
+  adr[27] = sb + 8192 + lane * 4;                                                           // CW: ... written (every wave the same 256 bytes)
   {
     const int row = 8 * wave + (lane >> 3), x = (row >> 1) & 7, f = ((x & 1) << 2) | (x >> 1), chunk = (lane & 7) ^ f;   // source-side swizzle of tile_off
-    adr[24] = (uint32_t)(row * (int)a.ldq + chunk * 8) * 2u;                                // QOFF / DOOFF: byte offsets of this lane's 16 B of the DMA piece
-    adr[25] = (uint32_t)(row * (int)a.lddo + chunk * 8) * 2u;
+    adr[28] = (uint32_t)(row * (int)a.ldq + chunk * 8) * 2u;                                // QOFF / DOOFF: byte offsets of this lane's 16 B of the DMA piece
+    adr[29] = (uint32_t)(row * (int)a.lddo + chunk * 8) * 2u;
   }
-  adr[26] = (uint32_t)(lane & 31) * 4u;                                                     // COFF
-  u32x32 aox;                                                                               // v192..v223; AO = v212..v219: byte offsets of the 8 atomics
-#pragma unroll
-  for (int i = 0; i < 32; ++i) aox[i] = 0u;
-  {
-    const uint32_t rowb = (uint32_t)(a.H * D) * 4u;
-    const uint32_t aoffb = (uint32_t)((4 * g4) * (a.H * D) + wave * 16 + ip) * 4u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) aox[20 + i] = aoffb + (uint32_t)(16 * (i >> 2) + (i & 3)) * rowb;
-  }
-  // loop state: pointers of the SECOND pair (the first is staged above), dQ rows of the first
-  const int h1 = a.H > 1 ? 1 : 0, qb1 = qb_begin + (a.H > 1 ? 0 : 1);
+  adr[30] = (uint32_t)(lane & 31) * 4u;                                                     // COFF
+  // loop state: bases = the part's FIRST pair (the lowest address of each tensor's part: the running 32-bit offsets stay non-negative); the
+  // request offsets start at the second pair (the first is staged above), the dQ offsets at the first
   const long hn = (long)b * a.H * a.N;
   auto uni = [](uint64_t x) {                                                               // block-uniform by construction; tell hipcc (physical SGPR operands)
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32) |      // (the builtin returns int: widen it unsigned)
            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
   };
-  uint64_t pq = uni((uint64_t)(a.q + ((long)b * a.N + qb1 * 32) * a.ldq + h1 * D));
-  uint64_t pdo = uni((uint64_t)(a.dout + ((long)b * a.N + qb1 * 32) * a.lddo + h1 * D));
-  uint64_t pls = uni((uint64_t)(a.lse2 + hn + (long)h1 * a.N + qb1 * 32));
-  uint64_t pdl = uni((uint64_t)(a.delta + hn + (long)h1 * a.N + qb1 * 32));
-  uint64_t pdq = uni((uint64_t)(dq32 + ((long)b * a.N + qb_begin * 32) * (a.H * D)));
+  const uint64_t pq = uni((uint64_t)(a.q + ((long)b * a.N + qb_begin * 32) * a.ldq));
+  const uint64_t pdo = uni((uint64_t)(a.dout + ((long)b * a.N + qb_begin * 32) * a.lddo));
+  const uint64_t pls = uni((uint64_t)(a.lse2 + hn + qb_begin * 32));
+  const uint64_t pdl = uni((uint64_t)(a.delta + hn + qb_begin * 32));
+  const uint64_t pdq = uni((uint64_t)(dq32 + ((long)b * a.N + qb_begin * 32) * (a.H * D)));
   const uint64_t wq = uni((uint64_t)((32 * a.ldq - (long)(a.H - 1) * D) * 2)), wdo = uni((uint64_t)((32 * a.lddo - (long)(a.H - 1) * D) * 2));
   const uint64_t wls = uni((uint64_t)((32 - (long)(a.H - 1) * a.N) * 4)), wdq = uni((uint64_t)((32L * a.H * D - (long)(a.H - 1) * D) * 4));
+  adr[28] += (uint32_t)(a.H > 1 ? (uint64_t)(D * 2) : wq);                                 // second pair: the next head, or (one head) the next block
+  adr[29] += (uint32_t)(a.H > 1 ? (uint64_t)(D * 2) : wdo);
+  adr[30] += (uint32_t)(a.H > 1 ? (uint64_t)a.N * 4u : wls);
   uint32_t cnt = __builtin_amdgcn_readfirstlane((uint32_t)(niter / 2));
+  uint32_t srem = __builtin_amdgcn_readfirstlane((uint32_t)(qb_per - 1 - (a.H > 1 ? 0 : 1)));    // block steps left for the request offsets (they sit at the second pair)
   const uint32_t hh = __builtin_amdgcn_readfirstlane((uint32_t)a.H), n4 = __builtin_amdgcn_readfirstlane((uint32_t)a.N * 4u);
+  const uint32_t rowb = __builtin_amdgcn_readfirstlane((uint32_t)(a.H * D) * 4u);
+  const uint32_t skof = __builtin_amdgcn_readfirstlane((uint32_t)(2 * kStage + wave * 16384));   // RK - (row-fragment offsets of a stage tile)
   // (floats come out of VALU instructions, and hipcc folds __builtin_amdgcn_readfirstlane of a value it knows to be uniform: an opaque one)
   auto rfl = [](float x) { uint32_t r; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(r) : "v"(x)); return r; };
   const uint32_t cbits = rfl(c), nrc = rfl(-1.f / c);
@@ -1541,10 +1541,10 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512a_kernel(AttnArgs a, f
   f32x32 acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7;                                    // dK^T tiles 0..3, dV^T tiles 0..3 (the loop's a[0:255], copied to v[0:255] at its end)
   asm volatile(OSUF_BWD512A_ASM
                : "={v[0:31]}"(acc0), "={v[32:63]}"(acc1), "={v[64:95]}"(acc2), "={v[96:127]}"(acc3), "={v[128:159]}"(acc4), "={v[160:191]}"(acc5),
-                 "={v[192:223]}"(acc6), "={v[224:255]}"(acc7), "+{s[48:49]}"(pq), "+{s[50:51]}"(pdo), "+{s[52:53]}"(pls), "+{s[54:55]}"(pdl),
-                 "+{s[56:57]}"(pdq), "+{s60}"(cnt)
-               : "{v[0:31]}"(vf0), "{v[32:63]}"(vf1), "{v[224:255]}"(adr), "{v[192:223]}"(aox), "{s61}"(hh), "{s65}"(n4), "{s[66:67]}"(wq),
-                 "{s[68:69]}"(wdo), "{s[70:71]}"(wls), "{s[72:73]}"(wdq), "{s74}"(cbits), "{s75}"(nrc), "{s76}"(m0base)
+                 "={v[192:223]}"(acc6), "={v[224:255]}"(acc7), "+{s60}"(cnt), "+{s63}"(srem)
+               : "{v[0:31]}"(vf0), "{v[32:63]}"(vf1), "{v[224:255]}"(adr), "{s[48:49]}"(pq), "{s[50:51]}"(pdo), "{s[52:53]}"(pls), "{s[54:55]}"(pdl),
+                 "{s[56:57]}"(pdq), "{s61}"(hh), "{s65}"(n4), "{s66}"((uint32_t)wq), "{s68}"((uint32_t)wdo), "{s70}"((uint32_t)wls), "{s72}"((uint32_t)wdq),
+                 "{s74}"(cbits), "{s75}"(nrc), "{s76}"(m0base), "{s77}"(skof), "{s80}"(rowb)
                : OSUF_BWD512A_CLOBBERS);
   const f32x32 dkv[8] = {acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7};
 #pragma unroll
@@ -1999,7 +1999,9 @@ extern "C" int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long l
     hipError_t e = hipMemsetAsync(dq32, 0, (size_t)dq_bytes, stream);
     if (e != hipSuccess) return (int)e;
   }
-  if (use512 && dq_mode == OSUF_DQ_ATOMIC_512A) {
+  // the 512-key sweep runs its hand-placed loop wherever that loop's shape rules hold (every UNet level does), the compiled loop elsewhere
+  const bool use512a = use512 && (dq_mode == OSUF_DQ_ATOMIC_512A || (dq_mode == OSUF_DQ_ATOMIC && fused512a_ok(a, N)));
+  if (use512a) {
     if (!fused512a_ok(a, N)) return OSUF_EUNSUPPORTED;
     const int lds = 2 * (4096 + 4096 + 256) + 65536 + 2 * 32768;
     static bool attr512a = false;

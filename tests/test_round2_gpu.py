@@ -45,7 +45,8 @@ def test_fused_attention_backward_beyond_eight_samples():
     o, lse = ops.mqa_fwd(qkv, Bn, N, H, D, torch.bfloat16, D ** -0.5)
     assert rell2(o.float(), o_ref) < 5e-3
     for name, variant, qsplit in (("fused", ops.ATTN_FUSED, 0), ("fused-split2", ops.ATTN_FUSED, 2), ("fused-slabs", ops.ATTN_FUSED_SLABS, 0),
-                                  ("auto", ops.ATTN_AUTO, 0), ("fused512", ops.ATTN_FUSED512, 1), ("fused512-split4", ops.ATTN_FUSED512, 4)):
+                                  ("auto", ops.ATTN_AUTO, 0), ("fused512", ops.ATTN_FUSED512, 1), ("fused512-split4", ops.ATTN_FUSED512, 4),
+                                  ("fused512a", ops.ATTN_FUSED512A, 1), ("fused512a-split4", ops.ATTN_FUSED512A, 4)):
         dqkv = ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5, variant=variant, qsplit=qsplit)
         for bi in range(Bn):                                               # per sample: a mis-placed sample is an O(1) error on it alone
             e = rell2(dqkv[bi], g_ref[bi])
@@ -67,6 +68,8 @@ def test_every_attention_backward_kernel_vs_fp32_autograd(N):
              ("fused-slabs", ops.ATTN_FUSED_SLABS, 0), ("fused256", ops.ATTN_FUSED256, 0)]
     if N % 32 == 0:                                                    # round 3: the 4-wave, 512-keys-per-workgroup sweep (whole query blocks)
         cases += [("fused512", ops.ATTN_FUSED512, 1), ("fused512-split2", ops.ATTN_FUSED512, 2), ("fused512-auto", ops.ATTN_FUSED512, 0)]
+    if N % 512 == 0:                                                   # round 4: the same sweep with its generated, hand-placed loop (whole 512-key blocks)
+        cases += [("fused512a", ops.ATTN_FUSED512A, 1), ("fused512a-split2", ops.ATTN_FUSED512A, 2), ("fused512a-auto", ops.ATTN_FUSED512A, 0)]
     outs = {}
     for name, variant, qsplit in cases:
         dqkv = ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5, variant=variant, qsplit=qsplit)
@@ -79,6 +82,12 @@ def test_every_attention_backward_kernel_vs_fp32_autograd(N):
         outs[name] = dqkv
     # the kernels differ only in schedule / summation order
     assert rell2(outs["plain"], outs["pipe-unsplit"]) < 2e-3
+    if "fused512a" in outs:
+        # the hand-placed loop keeps every fragment map and the order of every accumulation of the compiled 512-key sweep: dK / dV bit for bit,
+        # dQ up to the order of its float atomics
+        for a_, b_ in (("fused512a", "fused512"), ("fused512a-split2", "fused512-split2")):
+            assert torch.equal(outs[a_][..., H * D:], outs[b_][..., H * D:]), a_
+            assert rell2(outs[a_][..., :H * D], outs[b_][..., :H * D]) < 1e-5, a_
     # the slab path adds the key blocks' partial dQ in a fixed order: bit-reproducible
     assert torch.equal(outs["fused-slabs"], ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5, variant=ops.ATTN_FUSED_SLABS))
     # fused RoPE-transpose epilogue of the pipelined kernels == the stand-alone rope_bwd kernel on their fp32 result

@@ -8,7 +8,8 @@ for spec in "$@"; do
   name=${spec%%=*}; drop=${spec#*=}
   D=$(mktemp -d /tmp/osuf_var.XXXX)
   cp osufusion_amd/csrc/*.hip osufusion_amd/csrc/*.hpp osufusion_amd/csrc/*.inc "$D/"
-  python tools/gen_attn_bwd512.py --drop "$drop" --out "$D/attn_bwd512_asm.inc" > /dev/null
+  if [[ "$drop" == @* ]]; then python tools/gen_attn_bwd512.py ${drop#@} --out "$D/attn_bwd512_asm.inc" > /dev/null   # name=@--flag: generator flags instead of a drop list
+  else python tools/gen_attn_bwd512.py --drop "$drop" --out "$D/attn_bwd512_asm.inc" > /dev/null; fi
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -c "$D/attn.hip" -o "$D/attn.o" 2>/dev/null &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "osufusion_amd/csrc/libosuf_hip_$name.so" "$D/attn.o" $(ls osufusion_amd/csrc/build/*.o | grep -v attn.hip.o) &&
     echo "built libosuf_hip_$name.so (drop: $drop)"; rm -rf "$D" ) &

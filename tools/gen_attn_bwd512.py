@@ -36,16 +36,21 @@ for i, a in enumerate(sys.argv):
 
 # ---- register map (arch VGPRs) -----------------------------------------------------------------------------------------------
 VF, QA, DA, TRD, TRQ, S, DP, PF, DF, KF = 0, 64, 80, 96, 112, 128, 144, 160, 168, 176
-DQB, DQA0, DQA1, ACC0, ACC1, AO, CL, CD, TMP0, TMP1 = 192, 196, 200, 204, 208, 212, 220, 221, 222, 223
-RS, RK, T, KO, EO, EW, CR, CW, QOFF, DOOFF, COFF = 224, 228, 232, 236, 238, 242, 246, 247, 248, 249, 250
+DQB, DQA0, DQA1, ACC0, ACC1 = 192, 196, 200, 204, 208
+CS = 212                          # -lse / c of the pair's 32 queries as this lane's accumulator rows: the C operand of every S chain's first MFMA
+AO, CL, CD = 228, 230, 231        # byte offsets of the atomics of the two query halves (rows: scalar bases); row constants of the next stage in flight
+RK, T, KO, EO, EW, CR, CW, QOFF, DOOFF, COFF, RTMP = 232, 236, 240, 242, 246, 250, 251, 252, 253, 254, 255
+TMP0, TMP1 = S, S + 1             # (scratch of the stage's row constants: S is dead between the last tile's dS and the next pair)
 # AGPRs: dK^T tile t, head-dim half dt at a[32 t + 16 dt ..+15]; dV^T at a[128 + 32 t + 16 dt ..]
 def DK(t, dt): return 32 * t + 16 * dt
 def DV(t, dt): return 128 + 32 * t + 16 * dt
 # SGPRs
-SQ, SDO, SLS, SDL, SDQC, SDQP = 48, 50, 52, 54, 56, 58          # 64-bit pointers (pairs): stage Q / dO / lse2 / delta, dQ rows of this / the previous pair
-SCNT, SH, SHS, SREM, SHD, SN4 = 60, 61, 62, 63, 64, 65
-SWQ, SWDO, SWLS, SWDQ = 66, 68, 70, 72                         # 64-bit wrap deltas (bytes) at the last head of a query block
-SC, SNRC, SM0, STMP, SMASK = 74, 75, 76, 77, 78                  # c = scale log2 e, -1/c, LDS byte address of this wave's 1-KiB DMA piece, tmp, lane mask (pair)
+SQ, SDO, SLS, SDL, SDQC = 48, 50, 52, 54, 56                   # 64-bit bases (pairs): Q / dO / lse2 / delta of the part's SECOND pair, dQ rows of its first
+SCNT, SH, SHS, SREM, SHD, SN4 = 60, 61, 62, 63, 64, 65          # loop trips, heads, heads left (stage), blocks left (stage), heads left (dQ), 4 N
+SWQ, SWDO, SWLS, SWDQ = 66, 68, 70, 72                         # wrap deltas (bytes, low words used) at the last head of a query block
+SD128, SDN4, SDQS = 58, 59, 90                                 # per-head steps of QOFF / DOOFF, of COFF, of AO (0 once past the last pair / in the first iteration)
+SC, SNRC, SM0, SKOF, SMASK = 74, 75, 76, 77, 78                  # c = scale log2 e, -1/c, LDS byte address of this wave's 1-KiB DMA piece, RK - RS, lane mask (pair)
+SROWB, SROW = 80, 82                                             # bytes per dQ row; s[82:89]... rows 0..3 of the part's first pair: s[82:83] .. s[88:89]
 # LDS map (bytes): [2 x (Q 4096 | dO 4096 | -lse/c 128 | -delta 128)] | K image 65536 | 2 x dS image 32768
 STAGE, KIMG, EIMG = 8448, 16896, 82432
 
@@ -66,6 +71,10 @@ def aset(base, n):
     return {("a", base + i) for i in range(n)}
 
 
+# 4-byte encodings (VOP1 / VOP2 _e32) leave the 8-byte instructions behind them (MFMA, DS, VOP3) on addresses = 4 mod 8
+E64 = "--e64" in sys.argv
+
+
 class Emitter:
     """Collects instructions; inserts s_waitcnt lgkmcnt / vmcnt for register dependences on outstanding LDS reads / global loads and s_nop
     for the MFMA hazards hipcc would have padded."""
@@ -83,6 +92,8 @@ class Emitter:
         self.nops = 0
         # symbolic dataflow (which value sits in which register), compared between the hand-ordered body and the list-scheduled one
         self.val = {}            # reg -> value id
+        self.look = set()        # registers the next few matrix instructions read (wait merging)
+        self.cold = []           # rarely taken scalar-branch targets, emitted behind the kernel's last instruction
         self.sinks = []          # LDS stores / atomics: (kind, ids ...)
         self.epoch = 0           # barriers passed (LDS contents differ between iterations)
         self.pepoch = [0, 0]     # advances of the stage pointers / of the dQ pointers so far
@@ -101,6 +112,8 @@ class Emitter:
 
     # -- low level
     def raw(self, text, kind):
+        if E64 and text.startswith("v_") and "_e32 " in text:    # every vector instruction 8 bytes long (see E64)
+            text = text.replace("_e32 ", "_e64 ", 1)
         self.lines.append(text)
         self.count[kind] = self.count.get(kind, 0) + 1
         self.ws += 1
@@ -115,6 +128,8 @@ class Emitter:
             n -= k
 
     def _wait_regs(self, regs):
+        if self.look and (any(w & regs for w in self.lds)):
+            regs = regs | self.look                               # a wait is due anyway: let it cover what the next matrix instructions read
         need_l = None
         for i, w in enumerate(self.lds):
             if w & regs:
@@ -214,8 +229,9 @@ class Emitter:
         # (A and B fragments are register quadruples at distinct bases: tag each source with its role)
         import hashlib
         key = repr(("mfma", big, tuple(self.vid(r) for r in sorted(a)), tuple(self.vid(r) for r in sorted(b))))
+        csrc = sorted(c) if c else []
         for j, r in enumerate(sorted(dst)):
-            cj = self.vid(r) if c else 0
+            cj = self.vid(csrc[j]) if c else 0
             self.val[r] = hashlib.md5((key + repr(cj) + str(j)).encode()).hexdigest()[:16]
         for r in dst:
             self.mfma_ready[r] = self.ws + (self.MFMA32_WS if big else self.MFMA16_WS)
@@ -233,7 +249,8 @@ class Emitter:
     def mfma32(self, dst, a, b, agpr=False, c=None):
         d = ar(dst, 16) if agpr else vr(dst, 16)
         dset = aset(dst, 16) if agpr else vset(dst, 16)
-        self.mfma(True, dset, vset(a, 4), vset(b, 4), dset, f"v_mfma_f32_32x32x16_bf16 {d}, {vr(a, 4)}, {vr(b, 4)}, {d}")
+        cs = dset if c is None else vset(c, 16)
+        self.mfma(True, dset, vset(a, 4), vset(b, 4), cs, f"v_mfma_f32_32x32x16_bf16 {d}, {vr(a, 4)}, {vr(b, 4)}, {d if c is None else vr(c, 16)}")
 
     def mfma16(self, dst, a, b, zero):
         d = vr(dst, 4)
@@ -284,7 +301,17 @@ def ds_mul(e, r):
 
 
 def const_s(e, st, g):
-    e.rd128(S + 4 * g, CR, st + 32 * g)
+    e.rd128(CS + 4 * g, CR, st + 32 * g)
+
+
+def rs_read(e, dst, ks, imm):
+    """row fragment ks of a stage tile: the lane offset is RK[ks] less the K rows' base (a register pair saved per fragment)"""
+    e.valu(f"v_subrev_u32_e32 {vr(RTMP)}, s{SKOF}, {vr(RK + ks)}", vset(RK + ks), vset(RTMP))
+    e.rd128(dst, RTMP, imm)
+
+
+def s_mfma(e, ks):
+    e.mfma32(S, QA + 4 * ks, KF + 4 * ks, c=CS if ks == 0 else None)
 
 
 def const_dp(e, st, g):
@@ -318,48 +345,59 @@ def merge(*gaplists):
 
 
 def advance_stage_pointers(e, tag):
-    """stage pointers -> the pair after the one just requested (clamped at the last pair)"""
+    """The request offsets (QOFF, DOOFF: this lane's bytes of the DMA pieces; COFF: its row constant) move on to the pair after the one just
+    requested: +1 head, or at a block's last head on to the next query block; past the last pair they stop (deltas 0)."""
     e.pepoch[0] += 1
     L = f"{tag}"
-    e.salu(f"s_cmp_eq_u32 s{SREM}, 0", cond=True)
-    e.salu(f"s_cbranch_scc1 .Lsd{L}%=", cond=True)
-    e.salu(f"s_sub_u32 s{SREM}, s{SREM}, 1", cond=True)
-    e.salu(f"s_add_u32 s{SHS}, s{SHS}, 1", cond=True)
-    e.salu(f"s_cmp_eq_u32 s{SHS}, s{SH}", cond=True)
-    e.salu(f"s_cbranch_scc1 .Lsw{L}%=", cond=True)
-    for p, d in ((SQ, "128"), (SDO, "128"), (SLS, f"s{SN4}"), (SDL, f"s{SN4}")):
-        e.salu(f"s_add_u32 s{p}, s{p}, {d}", cond=True)
-        e.salu(f"s_addc_u32 s{p + 1}, s{p + 1}, 0", cond=True)
-    e.salu(f"s_branch .Lsd{L}%=", cond=True)
-    e.lines.append(f".Lsw{L}%=:")
-    e.salu(f"s_mov_b32 s{SHS}, 0", cond=True)
-    for p, w in ((SQ, SWQ), (SDO, SWDO), (SLS, SWLS), (SDL, SWLS)):
-        e.salu(f"s_add_u32 s{p}, s{p}, s{w}", cond=True)
-        e.salu(f"s_addc_u32 s{p + 1}, s{p + 1}, s{w + 1}", cond=True)
+    e.salu(f"s_sub_u32 s{SHS}, s{SHS}, 1")                         # heads left in the block; borrow -> next block
+    e.salu(f"s_cbranch_scc1 .Lsw{L}%=")
+    e.valu(f"v_add_u32_e32 {vr(QOFF)}, s{SD128}, {vr(QOFF)}", vset(QOFF), vset(QOFF))
+    e.valu(f"v_add_u32_e32 {vr(DOOFF)}, s{SD128}, {vr(DOOFF)}", vset(DOOFF), vset(DOOFF))
+    e.valu(f"v_add_u32_e32 {vr(COFF)}, s{SDN4}, {vr(COFF)}", vset(COFF), vset(COFF))
+    e.cold.append([f".Lsw{L}%=:",
+                   f"s_sub_u32 s{SREM}, s{SREM}, 1",               # blocks left; borrow -> that was the last pair
+                   f"s_cbranch_scc1 .Lse{L}%=",
+                   f"s_sub_u32 s{SHS}, s{SH}, 1",
+                   f"v_add_u32_e32 {vr(QOFF)}, s{SWQ}, {vr(QOFF)}",
+                   f"v_add_u32_e32 {vr(DOOFF)}, s{SWDO}, {vr(DOOFF)}",
+                   f"v_add_u32_e32 {vr(COFF)}, s{SWLS}, {vr(COFF)}",
+                   f"s_branch .Lsd{L}%=",
+                   f".Lse{L}%=:",
+                   f"s_mov_b32 s{SD128}, 0",
+                   f"s_mov_b32 s{SDN4}, 0",
+                   f"s_mov_b32 s{SHS}, 0x7fffffff",
+                   f"s_branch .Lsd{L}%="])
     e.lines.append(f".Lsd{L}%=:")
 
 
 def advance_dq_pointers(e, tag):
+    """AO (this lane's byte offsets of the atomics) moves on to the pair whose dQ the next iteration finishes; in the very first iteration the
+    step is 0 (its atomics added the zero image to the first pair's rows, which the second iteration adds to for real)."""
     L = f"{tag}"
     e.pepoch[1] += 1
-    e.salu(f"s_mov_b64 s[{SDQP}:{SDQP + 1}], s[{SDQC}:{SDQC + 1}]")
-    e.salu(f"s_add_u32 s{SHD}, s{SHD}, 1", cond=True)
-    e.salu(f"s_cmp_eq_u32 s{SHD}, s{SH}", cond=True)
-    e.salu(f"s_cbranch_scc1 .Lqw{L}%=", cond=True)
-    e.salu(f"s_add_u32 s{SDQC}, s{SDQC}, 256", cond=True)
-    e.salu(f"s_addc_u32 s{SDQC + 1}, s{SDQC + 1}, 0", cond=True)
-    e.salu(f"s_branch .Lqd{L}%=", cond=True)
-    e.lines.append(f".Lqw{L}%=:")
-    e.salu(f"s_mov_b32 s{SHD}, 0", cond=True)
-    e.salu(f"s_add_u32 s{SDQC}, s{SDQC}, s{SWDQ}", cond=True)
-    e.salu(f"s_addc_u32 s{SDQC + 1}, s{SDQC + 1}, s{SWDQ + 1}", cond=True)
+    e.salu(f"s_sub_u32 s{SHD}, s{SHD}, 1")
+    e.salu(f"s_cbranch_scc1 .Lqw{L}%=")
+    e.valu(f"v_add_u32_e32 {vr(AO)}, s{SDQS}, {vr(AO)}", vset(AO), vset(AO))
+    e.valu(f"v_add_u32_e32 {vr(AO + 1)}, s{SDQS}, {vr(AO + 1)}", vset(AO + 1), vset(AO + 1))
+    e.salu(f"s_movk_i32 s{SDQS}, 256")
+    e.cold.append([f".Lqw{L}%=:",
+                   f"s_sub_u32 s{SHD}, s{SH}, 1",
+                   f"v_add_u32_e32 {vr(AO)}, s{SWDQ}, {vr(AO)}",
+                   f"v_add_u32_e32 {vr(AO + 1)}, s{SWDQ}, {vr(AO + 1)}",
+                   f"s_branch .Lqd{L}%="])
     e.lines.append(f".Lqd{L}%=:")
+
+
+def atomic(e, i):
+    """row i & 3 of query half i >> 2"""
+    acc = (ACC0 if i < 4 else ACC1) + (i & 3)
+    base = SROW + 2 * (i & 3)
+    e.vmem(f"global_atomic_add_f32 {vr(AO + (i >> 2))}, {vr(acc)}, s[{base}:{base + 1}]", vset(AO + (i >> 2)) | vset(acc), set(), "atomic")
 
 
 def atomics(e):
     for i in range(8):
-        acc = (ACC0 if i < 4 else ACC1) + (i & 3)
-        e.vmem(f"global_atomic_add_f32 {vr(AO + i)}, {vr(acc)}, s[{SDQP}:{SDQP + 1}]", vset(AO + i) | vset(acc), set(), "atomic")
+        atomic(e, i)
 
 
 def dk3_mfma(i):
@@ -377,9 +415,9 @@ def body(e, sg, tag):
     rd_s = [F(const_s, st, g) for g in range(4)]
     rd_qk = []
     for ks in range(4):
-        rd_qk.append(lambda ks=ks: e.rd128(QA + 4 * ks, RS + ks, st))
+        rd_qk.append(lambda ks=ks: rs_read(e, QA + 4 * ks, ks, st))
         rd_qk.append(lambda ks=ks: e.rd128(KF + 4 * ks, RK + ks, 0))
-    rd_dp = [F(const_dp, st, g) for g in range(4)] + [(lambda ks=ks: e.rd128(DA + 4 * ks, RS + ks, st + 4096)) for ks in range(4)]
+    rd_dp = [F(const_dp, st, g) for g in range(4)] + [(lambda ks=ks: rs_read(e, DA + 4 * ks, ks, st + 4096)) for ks in range(4)]
     dq_reads(e, er, 0)                                                                      # (first: k-step 0 runs right behind the two MFMAs)
     for f in rd_s + rd_qk[:4]:
         f()
@@ -399,7 +437,7 @@ def body(e, sg, tag):
     # ---- S(0), dP(0) with the transposed fragments of the pair and exp2 of tile 0 beside them
     trd = [(lambda s2=s2, dt=dt: tr_frag(e, TRD + 8 * s2 + 4 * dt, st + 4096, s2, dt)) for s2 in range(2) for dt in range(2)]
     trq = [(lambda s2=s2, dt=dt: tr_frag(e, TRQ + 8 * s2 + 4 * dt, st, s2, dt)) for s2 in range(2) for dt in range(2)]
-    spread([(lambda ks=ks: e.mfma32(S, QA + 4 * ks, KF + 4 * ks)) for ks in range(4)], [[trd[0]], [trd[1]], [trd[2]], [trd[3]]])
+    spread([(lambda ks=ks: s_mfma(e, ks)) for ks in range(4)], [[trd[0]], [trd[1]], [trd[2]], [trd[3]]])
     advance_stage_pointers(e, tag)
     dq_mma(e, False)                                                                        # k-step 1
     dq_reads(e, er, 2)
@@ -418,9 +456,6 @@ def body(e, sg, tag):
         cdf = [F(cvt, DF + j, DP + 2 * j) for j in range(8)]
         g1 = [pf1 + muls[0:2], muls[2:8], muls[8:14], muls[14:16] + cdf[0:4]]
         if not last:
-            g1[1] += [F(const_s, st, 0)]
-            g1[2] += [F(const_s, st, 1), F(const_s, st, 2)]
-            g1[3] += [F(const_s, st, 3)]
             for ks in range(4):
                 g1[ks] += [lambda ks=ks: e.rd128(KF + 4 * ks, RK + ks, (t + 1) * 4096)]
         spread([(lambda s2=s2, dt=dt: e.mfma32(DV(t, dt), TRD + 8 * s2 + 4 * dt, PF + 4 * s2, agpr=True)) for s2 in range(2) for dt in range(2)], g1)
@@ -435,7 +470,7 @@ def body(e, sg, tag):
             break
         # ---- G2(t): S(t+1) | dS rows -> image, dP row constants
         g2 = [[wr[0], F(const_dp, st, 0)], [wr[1], F(const_dp, st, 1)], [wr[2], F(const_dp, st, 2)], [wr[3], F(const_dp, st, 3)]]
-        spread([(lambda ks=ks: e.mfma32(S, QA + 4 * ks, KF + 4 * ks)) for ks in range(4)], g2)
+        spread([(lambda ks=ks: s_mfma(e, ks)) for ks in range(4)], g2)
         dq_mma(e, False)
         kstep += 1
         dq_reads(e, er, kstep)
@@ -461,10 +496,10 @@ def body(e, sg, tag):
     for f in wr:
         f()
     e.wait(vm=0)                                                                            # the row constants requested at the head (and with
-    e.valu(f"v_mul_f32_e32 {vr(TMP0)}, s{SNRC}, {vr(CL)}", vset(CL), vset(TMP0))            #  them every older operation: last iteration's atomics)
-    e.valu(f"v_mul_f32_e32 {vr(TMP1)}, -1.0, {vr(CD)}", vset(CD), vset(TMP1))
-    e.valu(f"v_cndmask_b32_e64 {vr(TMP0)}, {vr(TMP1)}, {vr(TMP0)}, s[{SMASK}:{SMASK + 1}]", vset(TMP0) | vset(TMP1), vset(TMP0))
-    e.ds_write(f"ds_write_b32 {vr(CW)}, {vr(TMP0)} offset:{stw}", vset(CW) | vset(TMP0), "ds_write")
+    e.valu(f"v_mul_f32_e32 {vr(CL)}, s{SNRC}, {vr(CL)}", vset(CL), vset(CL))                #  them every older operation: last iteration's atomics)
+    e.valu(f"v_mul_f32_e32 {vr(CD)}, -1.0, {vr(CD)}", vset(CD), vset(CD))
+    e.valu(f"v_cndmask_b32_e64 {vr(CL)}, {vr(CD)}, {vr(CL)}, s[{SMASK}:{SMASK + 1}]", vset(CL) | vset(CD), vset(CL))
+    e.ds_write(f"ds_write_b32 {vr(CW)}, {vr(CL)} offset:{stw}", vset(CW) | vset(CL), "ds_write")
     dk3_mfma(1)(e)
     atomics(e)
     advance_dq_pointers(e, tag)
@@ -487,6 +522,17 @@ C_V, C_EXP, C_L, C_W = 4, 8, 5, 6
 BUDGET_BIG, BUDGET_SMALL = 30, 10
 LDS_CAP_BIG, LDS_CAP_SMALL = 3, 1
 LAT = 3                                                           # an LDS read sits at least this many slots ahead of its consumer
+KSP = 4                                                           # 32x32x16 MFMAs per dQ k-step
+CWLATE = "--cwlate" in sys.argv
+for _i, _a in enumerate(sys.argv):
+    if _a == "--ksp":
+        KSP = int(sys.argv[_i + 1])                                # tuning knobs of the placement (tools/build_variants.sh name=@"--lat 5 --ldscap 4,2")
+    if _a == "--lat":
+        LAT = int(sys.argv[_i + 1])
+    if _a == "--ldscap":
+        LDS_CAP_BIG, LDS_CAP_SMALL = map(int, sys.argv[_i + 1].split(","))
+    if _a == "--budget":
+        BUDGET_BIG, BUDGET_SMALL = map(int, sys.argv[_i + 1].split(","))
 GAPLOG = []
 
 
@@ -497,46 +543,59 @@ def body_sched(e, sg, tag):
     ew, er = sg * 32768, (1 - sg) * 32768
     slots = []                                                    # (name, emit function, gap budget)
 
-    def big(name, fn):
-        slots.append((name, fn, BUDGET_BIG))
+    sregs = []                                                    # per slot: the registers its matrix instruction reads out of LDS loads
+
+    bigs = []
+
+    def big(name, fn, regs=frozenset()):
+        bigs.append((name, fn, set(regs)))
 
     def kstep(j):
         slots.append((f"Q{j}a", lambda: None if "dq" in DROP else e.mfma16(ACC0, DQA0, DQB, j == 0), BUDGET_SMALL))
+        sregs.append(vset(DQA0, 4) | vset(DQB, 4))
         slots.append((f"Q{j}b", lambda: None if "dq" in DROP else e.mfma16(ACC1, DQA1, DQB, j == 0), BUDGET_SMALL))
+        sregs.append(vset(DQA1, 4) | vset(DQB, 4))
 
     def group_s(t):
         for ks in range(4):
-            big(f"S{t}.{ks}", lambda ks=ks: e.mfma32(S, QA + 4 * ks, KF + 4 * ks))
+            big(f"S{t}.{ks}", lambda ks=ks: s_mfma(e, ks), vset(QA + 4 * ks, 4) | vset(KF + 4 * ks, 4) | (vset(CS, 16) if ks == 0 else set()))
 
     def group_p(t):
         for ks in range(4):
-            big(f"P{t}.{ks}", lambda ks=ks: e.mfma32(DP, DA + 4 * ks, VF + 16 * t + 4 * ks))
+            big(f"P{t}.{ks}", lambda ks=ks: e.mfma32(DP, DA + 4 * ks, VF + 16 * t + 4 * ks), vset(DA + 4 * ks, 4) | (vset(DP, 16) if ks == 0 else set()))
 
     def group_v(t):
         for i in range(4):
             s2, dt = i >> 1, i & 1
-            big(f"V{t}.{i}", lambda s2=s2, dt=dt: e.mfma32(DV(t, dt), TRD + 8 * s2 + 4 * dt, PF + 4 * s2, agpr=True))
+            big(f"V{t}.{i}", lambda s2=s2, dt=dt: e.mfma32(DV(t, dt), TRD + 8 * s2 + 4 * dt, PF + 4 * s2, agpr=True), vset(TRD + 8 * s2 + 4 * dt, 4))
 
     def group_k(t):
         for i in range(4):
             s2, dt = i >> 1, i & 1
-            big(f"K{t}.{i}", lambda s2=s2, dt=dt: e.mfma32(DK(t, dt), TRQ + 8 * s2 + 4 * dt, DF + 4 * s2, agpr=True))
+            big(f"K{t}.{i}", lambda s2=s2, dt=dt: e.mfma32(DK(t, dt), TRQ + 8 * s2 + 4 * dt, DF + 4 * s2, agpr=True), vset(TRQ + 8 * s2 + 4 * dt, 4))
 
     big("K3c", lambda: dk3_mfma(2)(e))
     big("K3d", lambda: dk3_mfma(3)(e))
-    kstep(0)
-    group_s(0); kstep(1)
-    group_p(0); kstep(2)
-    j = 3
+    group_s(0)
+    group_p(0)
     for t in range(4):
-        group_v(t); kstep(j); j += 1
+        group_v(t)
         if t < 3:
-            group_s(t + 1); kstep(j); j += 1
-            group_k(t); kstep(j); j += 1
-            group_p(t + 1); kstep(j); j += 1
-    assert j == 16
+            group_s(t + 1)
+            group_k(t)
+            group_p(t + 1)
     big("K3a", lambda: dk3_mfma(0)(e))
     big("K3b", lambda: dk3_mfma(1)(e))
+    # one dQ k-step (two 16x16x32) behind every KSP-th 32x32x16: KSP = 4 spreads the sixteen k-steps over the whole iteration, KSP = 3 ends them
+    # after 48 of its 66 matrix instructions, so that the eight float atomics of the finished tiles can leave one at a time behind the rest
+    kpos = {2 + KSP * q for q in range(16)}
+    j = 0
+    for n, (name, fn, regs) in enumerate(bigs, 1):
+        slots.append((name, fn, BUDGET_BIG))
+        sregs.append(regs)
+        if n in kpos:
+            kstep(j); j += 1
+    assert j == 16, j
     idx = {n: i for i, (n, _, _) in enumerate(slots)}
     items = []
 
@@ -549,6 +608,8 @@ def body_sched(e, sg, tag):
         add(name + "h", (lambda: e.rdtr(dst + 2, T + 2 * dt + 1, tile_imm + 2048 * s2 + 1024)), C_L, "L", **kw)
 
     def add_dq(jq, after, before_a, before_b):
+        if "dqreads" in DROP:                                     # triage: the dQ MFMAs on stale operands
+            return
         for i, (dst, adr, imm) in enumerate(((DQB, KO, jq * 4096), (DQA0, EO, er + jq * 2048), (DQA1, EO + 2, er + jq * 2048))):
             for h in range(2):
                 add(f"dqr{jq}.{i}{h}", (lambda dst=dst, adr=adr, imm=imm, h=h: e.rdtr(dst + 2 * h, adr + h, imm)), C_L, "L",
@@ -560,11 +621,11 @@ def body_sched(e, sg, tag):
     for g in range(4):
         add(f"cs0.{g}", (lambda g=g: const_s(e, st, g)), C_L, "L", before=idx["S0.0"] - LAT)
     for ks in range(4):
-        add(f"qa.{ks}", (lambda ks=ks: e.rd128(QA + 4 * ks, RS + ks, st)), C_L, "L", before=idx[f"S0.{ks}"] - LAT)
+        add(f"qa.{ks}", (lambda ks=ks: rs_read(e, QA + 4 * ks, ks, st)), C_L + C_V, "L", before=idx[f"S0.{ks}"] - LAT)
     for g in range(4):
         add(f"cd0.{g}", (lambda g=g: const_dp(e, st, g)), C_L, "L", before=idx["P0.0"] - LAT)
     for ks in range(4):
-        add(f"da.{ks}", (lambda ks=ks: e.rd128(DA + 4 * ks, RS + ks, st + 4096)), C_L, "L", before=idx[f"P0.{ks}"] - LAT)
+        add(f"da.{ks}", (lambda ks=ks: rs_read(e, DA + 4 * ks, ks, st + 4096)), C_L + C_V, "L", before=idx[f"P0.{ks}"] - LAT)
     for i in range(4):
         s2, dt = i >> 1, i & 1
         add_tr(f"trd.{i}", TRD + 8 * s2 + 4 * dt, st + 4096, s2, dt, before=idx[f"V0.{i}"] - LAT)
@@ -585,6 +646,7 @@ def body_sched(e, sg, tag):
     for t in range(4):
         s_done, p_done = idx[f"S{t}.3"] + 3, idx[f"P{t}.3"] + 3     # first gap in which a VALU reader of the chain's result may sit (the emitter pads to 12 wait states)
         vdead = lambda r: idx[f"V{t}.0"] if r < 8 else idx[f"V{t}.2"]
+        snext = idx[f"S{t + 1}.0"] if t < 3 else 10 ** 6          # readers of S sit before the next tile's S chain
         for jj in range(8):
             add(f"mm{t}.{jj}", (lambda jj=jj: (mul_exp(e, 2 * jj), mul_exp(e, 2 * jj + 1))), 2 * C_V, "V", after=s_done, before=vdead(2 * jj))
             add(f"ee{t}.{jj}", (lambda jj=jj: (exp(e, 2 * jj), exp(e, 2 * jj + 1))), 2 * C_EXP, "V", deps=(f"mm{t}.{jj}",), before=vdead(2 * jj))
@@ -596,13 +658,12 @@ def body_sched(e, sg, tag):
         for g in range(4):
             for h in range(2):
                 add(f"dm{t}.{g}{h}", (lambda g=g, h=h: (ds_mul(e, 4 * g + 2 * h), ds_mul(e, 4 * g + 2 * h + 1))), 2 * C_V, "V", after=p_done,
-                    deps=(f"ee{t}.{2 * g + h}",), before=kdead(g))
+                    deps=(f"ee{t}.{2 * g + h}",), before=min(kdead(g), snext))
             dfd = [f"dm{t}.{g}0", f"dm{t}.{g}1"] + ([f"dw{t - 1}.{g}"] if t > 0 else [])
             add(f"df{t}.{g}", (lambda g=g: [cvt(e, DF + 2 * g + q, DP + 4 * g + 2 * q) for q in range(2)]), 2 * C_V, "V", deps=dfd, before=kdead(g))
             add(f"dw{t}.{g}", (lambda g=g, t=t: e.ds_write(f"ds_write_b64 {vr(EW + g)}, {vr(DF + 2 * g, 2)} offset:{ew + t * 2048}", vset(EW + g) | vset(DF + 2 * g, 2))),
                 C_W, "L", deps=(f"df{t}.{g}",))
             if t < 3:
-                add(f"cs{t + 1}.{g}", (lambda g=g: const_s(e, st, g)), C_L, "L", deps=(f"dm{t}.{g}0", f"dm{t}.{g}1", f"pf{t}.{g}"), before=idx[f"S{t + 1}.0"] - LAT)
                 add(f"cd{t + 1}.{g}", (lambda g=g: const_dp(e, st, g)), C_L, "L", deps=(f"df{t}.{g}",), before=idx[f"P{t + 1}.0"] - LAT)
         for ks in range(4):                                       # K rows of the next tile (of tile 0 again for the next pair: the image is resident)
             tn = (t + 1) & 3
@@ -616,15 +677,15 @@ def body_sched(e, sg, tag):
 
     def cw():
         e.wait(vm=0)                                                                            # the row constants requested at the head (and with them
-        e.valu(f"v_mul_f32_e32 {vr(TMP0)}, s{SNRC}, {vr(CL)}", vset(CL), vset(TMP0))            #  every older operation: last iteration's atomics)
-        e.valu(f"v_mul_f32_e32 {vr(TMP1)}, -1.0, {vr(CD)}", vset(CD), vset(TMP1))
-        e.valu(f"v_cndmask_b32_e64 {vr(TMP0)}, {vr(TMP1)}, {vr(TMP0)}, s[{SMASK}:{SMASK + 1}]", vset(TMP0) | vset(TMP1), vset(TMP0))
-        e.ds_write(f"ds_write_b32 {vr(CW)}, {vr(TMP0)} offset:{stw}", vset(CW) | vset(TMP0), "ds_write")
-    add("cw", cw, 22, "O", after=idx["P3.2"], before=idx["K3a"])
+        e.valu(f"v_mul_f32_e32 {vr(CL)}, s{SNRC}, {vr(CL)}", vset(CL), vset(CL))                #  every older operation: last iteration's atomics)
+        e.valu(f"v_mul_f32_e32 {vr(CD)}, -1.0, {vr(CD)}", vset(CD), vset(CD))
+        e.valu(f"v_cndmask_b32_e64 {vr(CL)}, {vr(CD)}, {vr(CL)}, s[{SMASK}:{SMASK + 1}]", vset(CL) | vset(CD), vset(CL))
+        e.ds_write(f"ds_write_b32 {vr(CW)}, {vr(CL)} offset:{stw}", vset(CW) | vset(CL), "ds_write")
+    q15 = idx["Q15b"]
+    add("cw", cw, 22, "O", after=(len(slots) - 3) if CWLATE else max(q15 - 4, idx["P0.3"]), before=q15 + 2 if not CWLATE else 10 ** 6)
+    nleft = len(slots) - 1 - q15                                  # gaps behind the last k-step: the atomics leave one per gap where there are enough
     for i in range(8):
-        acc = (ACC0 if i < 4 else ACC1) + (i & 3)
-        add(f"atom.{i}", (lambda i=i, acc=acc: e.vmem(f"global_atomic_add_f32 {vr(AO + i)}, {vr(acc)}, s[{SDQP}:{SDQP + 1}]", vset(AO + i) | vset(acc), set(), "atomic")),
-            5, "O", after=idx["K3a"], deps=("cw",))
+        add(f"atom.{i}", (lambda i=i: atomic(e, i)), 5, "O", after=q15 + 1 + (i * max(nleft - 2, 0)) // 8, deps=("cw",))
     add("advq", (lambda: advance_dq_pointers(e, tag)), 8, "O", deps=[f"atom.{i}" for i in range(8)])
     for n, it in enumerate(items):
         it.order = n
@@ -665,8 +726,17 @@ def body_sched(e, sg, tag):
             last = pick.cls
         return used
 
+    pad = int(sys.argv[sys.argv.index("--pad") + 1]) if "--pad" in sys.argv else 0     # triage: extra vector instructions per 32x32x16 gap
+    LOOK = int(sys.argv[sys.argv.index("--look") + 1]) if "--look" in sys.argv else 2
     for k, (name, fn, budget) in enumerate(slots):
+        e.look = set().union(*sregs[k + 1:k + 1 + LOOK]) if LOOK else set()
         fn()
+        if budget == BUDGET_BIG:
+            for _ in range(pad):
+                e.raw(f"v_mov_b32_e32 {vr(RTMP)}, {vr(RTMP)}", "pad")
+            if "--padlds" in sys.argv:                            # triage: what an LDS instruction costs the issue (no data moved)
+                e.raw("ds_nop", "pad")
+                e.lds.append(set())
         u = fill(k, budget)
         GAPLOG.append((tag, name, budget, u))
     while pending:                                                # (what has no deadline inside the iteration: the last dS rows)
@@ -674,6 +744,7 @@ def body_sched(e, sg, tag):
         assert ready, [it.name for it in pending]
         ready[0].fn(); placed.add(ready[0].name); pending.remove(ready[0])
         GAPLOG.append((tag, "flush:" + ready[0].name, 0, ready[0].cost))
+    e.look = set()
     e.wait(lgkm=0)
     e.salu("s_barrier")
 
@@ -690,13 +761,17 @@ def generate():
         e.raw(f"v_mov_b32_e32 {vr(r)}, 0", "init")
     for ks in range(4):                                                                     # K rows of tile 0 (each iteration re-reads them for the next pair)
         e.rd128(KF + 4 * ks, RK + ks, 0)
-    e.salu(f"s_mov_b64 s[{SDQP}:{SDQP + 1}], s[{SDQC}:{SDQC + 1}]")
-    e.salu(f"s_mov_b32 s{SHD}, 0")
-    e.salu(f"s_mov_b32 s{SHS}, 1")
-    e.salu(f"s_cmp_eq_u32 s{SH}, 1")
+    e.salu(f"s_mov_b64 s[{SROW}:{SROW + 1}], s[{SDQC}:{SDQC + 1}]")                          # scalar bases of the four dQ rows a lane's atomics touch per query half
+    for r in range(1, 4):
+        e.salu(f"s_add_u32 s{SROW + 2 * r}, s{SROW + 2 * r - 2}, s{SROWB}")
+        e.salu(f"s_addc_u32 s{SROW + 2 * r + 1}, s{SROW + 2 * r - 1}, 0")
+    e.salu(f"s_mov_b32 s{SHD}, s{SH}")                                                       # dQ offsets: first step 0, then H - 1 steps of one head, then a block step
+    e.salu(f"s_mov_b32 s{SDQS}, 0")
+    e.salu(f"s_movk_i32 s{SD128}, 128")
+    e.salu(f"s_mov_b32 s{SDN4}, s{SN4}")
+    e.salu(f"s_sub_u32 s{SHS}, s{SH}, 2")                                                    # stage offsets sit at the second pair (head 1): H - 2 head steps left in its block
+    e.salu(f"s_cmp_eq_u32 s{SH}, 1")                                                         # (one head: the second pair opens the second block)
     e.salu(f"s_cselect_b32 s{SHS}, 0, s{SHS}")
-    e.salu(f"s_lshl_b32 s{SREM}, s{SCNT}, 1")
-    e.salu(f"s_sub_u32 s{SREM}, s{SREM}, 2")
     e.salu(f"s_mov_b32 s{SMASK}, -1")
     e.salu(f"s_mov_b32 s{SMASK + 1}, 0")
     # The loop's text must be valid for the state the back edge arrives in (MFMA results of the previous iteration still settling), which
@@ -705,7 +780,7 @@ def generate():
 
     def two_bodies(state):
         x = copy.deepcopy(state)
-        x.lines, x.count, x.nops = [], {}, 0
+        x.lines, x.count, x.nops, x.cold = [], {}, 0, []
         BODY(x, 0, "a")
         BODY(x, 1, "b")
         x.salu(f"s_sub_u32 s{SCNT}, s{SCNT}, 1")
@@ -740,6 +815,7 @@ def generate():
     for k in ("lds", "vm", "ws", "mfma_ready", "mfma_chain", "valu_ws"):
         setattr(e, k, copy.deepcopy(getattr(second, k)))
     e.nops += second.nops
+    e.cold = second.cold
     # ---- tail: the last pair's remaining dK MFMAs and its dQ
     dk3_mfma(2)(e)
     dk3_mfma(3)(e)
@@ -752,6 +828,10 @@ def generate():
     e.nop(20)                                                                               # every accumulator written back ...
     for i in range(256):                                                                    # ... then handed to the C++ epilogue in v0..v255 (a 1024-bit
         e.raw(f"v_accvgpr_read_b32 v{i}, a{i}", "fini")                                     #     AGPR tuple as an asm output makes hipcc 7.2 emit an illegal copy)
+    e.lines.append("s_branch .Lend%=")
+    for blk in e.cold:                                                                      # block / end-of-part steps of the running offsets (once per H pairs)
+        e.lines += blk
+    e.lines.append(".Lend%=:")
     return e, loop_len, loop_count, chk
 
 
@@ -766,7 +846,7 @@ def main():
             f.write(f'  "{l}\\n\\t" \\\n')
         f.write('  ""\n')
         cl = ", ".join(f'"v{i}"' for i in range(64, 192)) + ", " + ", ".join(f'"a{i}"' for i in range(256))
-        sc = ", ".join(f'"s{i}"' for i in (SDQP, SDQP + 1, SHS, SREM, SHD, STMP, SMASK, SMASK + 1))
+        sc = ", ".join(f'"s{i}"' for i in (SD128, SDN4, SDQS, SHS, SHD, SMASK, SMASK + 1) + tuple(range(SROW, SROW + 8)))
         f.write(f'#define OSUF_BWD512A_CLOBBERS "memory", "vcc", "scc", {sc}, {cl}\n')
     if "--stats" in sys.argv:
         per_pair = {k: v / 2 for k, v in loop_count.items() if k not in ("init", "fini")}
