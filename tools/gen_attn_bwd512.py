@@ -392,6 +392,9 @@ def atomic(e, i):
     """row i & 3 of query half i >> 2"""
     acc = (ACC0 if i < 4 else ACC1) + (i & 3)
     base = SROW + 2 * (i & 3)
+    if "atomstore" in DROP:                                       # triage: plain stores of the same shape instead of the float atomics
+        e.vmem(f"global_store_dword {vr(AO + (i >> 2))}, {vr(acc)}, s[{base}:{base + 1}]", vset(AO + (i >> 2)) | vset(acc), set(), "atomic")
+        return
     e.vmem(f"global_atomic_add_f32 {vr(AO + (i >> 2))}, {vr(acc)}, s[{base}:{base + 1}]", vset(AO + (i >> 2)) | vset(acc), set(), "atomic")
 
 
@@ -676,6 +679,8 @@ def body_sched(e, sg, tag):
     # ---- end of the iteration
 
     def cw():
+        if "vmwait" in DROP:                                                                    # triage: the wait alone (stale row constants)
+            e.vm.clear()
         e.wait(vm=0)                                                                            # the row constants requested at the head (and with them
         e.valu(f"v_mul_f32_e32 {vr(CL)}, s{SNRC}, {vr(CL)}", vset(CL), vset(CL))                #  every older operation: last iteration's atomics)
         e.valu(f"v_mul_f32_e32 {vr(CD)}, -1.0, {vr(CD)}", vset(CD), vset(CD))
