@@ -1066,6 +1066,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_skinny_kernel(GemmArgs g) {
 struct WgradArgs {
   const void* dY; const void* X; float* dW;
   float* ws;                       // optional [splits][taps][N1][N2] partial tiles (plain stores) instead of atomics
+  int ws_pk;                       // the partial tiles are bf16 pairs: dword [split][tap][n1 / 2][n2] = (row n1 even | row n1 + 1 << 16)  (round 4)
   long es;                         // element stride of n2 in dW (1, or `taps` for torch's (Cout, Cin, k) weight layout)
   long ldy, ldx, ldw, tapstride;
   int M, N1, N2, taps;
@@ -1255,6 +1256,25 @@ __device__ __forceinline__ void tn_big_store(const WgradArgs& g, const f32x16 (&
     const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
     return n1_0 + wr * 128 + (IL ? 4 * rho + i : i * 32 + rho);
   };
+  if (g.ws && g.ws_pk && !IL) {
+    // bf16 partial tiles: registers r, r + 1 (r even) are rows n1, n1 + 1 of this lane's column -> one dword; half the bytes and half the
+    // store instructions of the fp32 tiles (19 GB of partials per step were written here and read back by the reduce kernels)
+    uint32_t* out = reinterpret_cast<uint32_t*>(g.ws) + ((long)split * g.taps + t) * (g.N1 >> 1) * g.N2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n2 = n2_0 + wc * 64 + j * 32 + lr;
+        if (n2 < g.N2) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int n1 = n1_of(i, r);
+            if (n1 < g.N1) out[(long)(n1 >> 1) * g.N2 + n2] = pack_bf16x2(acc[i][j][r], acc[i][j][r + 1]);
+          }
+        }
+      }
+    return;
+  }
   if (g.ws) {
     float* out = g.ws + ((long)split * g.taps + t) * g.N1 * g.N2;
 #pragma unroll
@@ -1714,6 +1734,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_taps3_kernel(WgradArgs g) {
   }
 
   // partial tiles of this m-split ([split][tap][N1][N2], plain stores; summed by the wgrad_reduce kernels) or fp32 atomics into dW
+  if (g.ws && g.ws_pk) {                                             // bf16 pairs of rows (see tn_big_store)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      uint32_t* out = reinterpret_cast<uint32_t*>(g.ws) + ((long)split * 3 + t) * (g.N1 >> 1) * g.N2;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int n2 = n2_0 + wc * 32 + lr;
+        if (n2 < g.N2) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int n1 = n1_0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (n1 < g.N1) out[(long)(n1 >> 1) * g.N2 + n2] = pack_bf16x2(acc[i][t][r], acc[i][t][r + 1]);
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     float* out = g.ws ? g.ws + ((long)split * 3 + t) * g.N1 * g.N2 : g.dW + (long)t * g.tapstride;
@@ -2062,6 +2100,95 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* ws, flo
   }
 }
 
+// The reduce for bf16-pair partial tiles: a workgroup is 64 output groups x 4 split lanes (wave s sums splits s, s + 4, ... in two chains,
+// the four sums meet in LDS in the fixed order s = 0..3: deterministic); a group is 4 columns of a row PAIR: one 16-byte load per split gives
+// rows n1, n1 + 1 of columns 4 q .. 4 q + 3.  NT = taps a thread carries: 1 (group = (tap, pair, quad); LAYOUT 0, or any tap count in LAYOUT 1
+// with scattered stores) or 3 (LAYOUT 1, k3 convs: the twelve outputs of a row's quad are three 16-byte stores, as wgrad_reduce_kernel<1>).
+template <int LAYOUT, int NT>
+__global__ __launch_bounds__(256) void wgrad_reduce_pk_kernel(const uint32_t* ws, float* dW, int N1, int N2, int taps, int splits, int accumulate) {
+  __shared__ f32x4 red[3][2 * NT][64];
+  const int tq = threadIdx.x & 63, ts = threadIdx.x >> 6;
+  const long quads = N2 >> 2, per_tap = (long)(N1 >> 1) * quads, groups = NT == 3 ? per_tap : per_tap * taps;
+  const long gi = (long)blockIdx.x * 64 + tq, gc = min(gi, groups - 1);
+  const int t0 = NT == 3 ? 0 : (int)(gc / per_tap);
+  const long rem = gc - (long)t0 * per_tap;
+  const long p = rem / quads, q = rem - p * quads;
+  const long tile = (long)(N1 >> 1) * N2, stride = tile * taps;                              // dwords per (split, tap) / per split
+  const uint32_t* src = ws + (long)t0 * tile + p * N2 + 4 * q;
+  f32x4 ev[NT], od[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { ev[t] = f32x4{0.f, 0.f, 0.f, 0.f}; od[t] = ev[t]; }
+  for (int sidx = ts; sidx < splits; sidx += 4) {
+    u32x4 a[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a[t] = *reinterpret_cast<const u32x4*>(src + (long)sidx * stride + (long)t * tile);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ev[t][e] += __builtin_bit_cast(float, a[t][e] << 16);
+        od[t][e] += __builtin_bit_cast(float, a[t][e] & 0xffff0000u);
+      }
+  }
+  if (ts) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { red[ts - 1][2 * t][tq] = ev[t]; red[ts - 1][2 * t + 1][tq] = od[t]; }
+  }
+  __syncthreads();
+  if (ts == 0 && gi < groups) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      ev[t] = ((ev[t] + red[0][2 * t][tq]) + red[1][2 * t][tq]) + red[2][2 * t][tq];
+      od[t] = ((od[t] + red[0][2 * t + 1][tq]) + red[1][2 * t + 1][tq]) + red[2][2 * t + 1][tq];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long n1 = 2 * p + h;
+      if constexpr (NT == 3) {
+        const f32x4 a0 = h ? od[0] : ev[0], a1 = h ? od[1] : ev[1], a2 = h ? od[2] : ev[2];
+        f32x4* dst = reinterpret_cast<f32x4*>(dW + (n1 * N2 + 4 * q) * 3);
+        f32x4 o0 = {a0[0], a1[0], a2[0], a0[1]}, o1 = {a1[1], a2[1], a0[2], a1[2]}, o2 = {a2[2], a0[3], a1[3], a2[3]};
+        if (accumulate) { o0 += dst[0]; o1 += dst[1]; o2 += dst[2]; }
+        dst[0] = o0; dst[1] = o1; dst[2] = o2;
+      } else if constexpr (LAYOUT == 0) {
+        const f32x4 v = h ? od[0] : ev[0];
+        f32x4* dst = reinterpret_cast<f32x4*>(dW + ((long)t0 * N1 + n1) * N2 + 4 * q);
+        *dst = accumulate ? *dst + v : v;
+      } else {
+        const f32x4 v = h ? od[0] : ev[0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float* dst = dW + (n1 * N2 + 4 * q + e) * taps + t0;
+          *dst = accumulate ? *dst + v[e] : v[e];
+        }
+      }
+    }
+  }
+}
+
+// launches the reduce of the partial tiles of a split weight gradient: bf16 pairs (pk) or the fp32 tiles' kernels
+static void launch_wgrad_reduce(const WgradArgs& gb, float* dW, int N1, int N2, int taps, int sp, int out_layout, int accumulate, bool many_splits_ok,
+                                hipStream_t stream) {
+  const long n12 = (long)N1 * N2, n = n12 * taps;
+  if (gb.ws_pk) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(gb.ws);
+    const long per_tap = (long)(N1 >> 1) * (N2 >> 2);
+    if (out_layout == 1 && taps == 3) hipLaunchKernelGGL((wgrad_reduce_pk_kernel<1, 3>), dim3((int)((per_tap + 63) / 64)), dim3(256), 0, stream, w, dW, N1, N2, taps, sp, accumulate);
+    else if (out_layout == 1) hipLaunchKernelGGL((wgrad_reduce_pk_kernel<1, 1>), dim3((int)((per_tap * taps + 63) / 64)), dim3(256), 0, stream, w, dW, N1, N2, taps, sp, accumulate);
+    else hipLaunchKernelGGL((wgrad_reduce_pk_kernel<0, 1>), dim3((int)((per_tap * taps + 63) / 64)), dim3(256), 0, stream, w, dW, N1, N2, taps, sp, accumulate);
+    return;
+  }
+  const long groups = out_layout == 1 ? n12 / 4 : n / 4;            // float4 output groups (x taps partial reads each in layout 1)
+  long blocks = (groups + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (sp >= 8 && blocks < 512 && many_splits_ok) {                  // many splits, few outputs: four split lanes per output group
+    const long b4 = (groups + 63) / 64;
+    if (out_layout == 1) hipLaunchKernelGGL(wgrad_reduce4_kernel<1>, dim3((int)b4), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
+    else hipLaunchKernelGGL(wgrad_reduce4_kernel<0>, dim3((int)b4), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
+  } else if (out_layout == 1) hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((int)blocks), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
+  else hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3((int)blocks), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
+}
+
 // column sums: out[n] += sum_m Y[m][n]   (bias gradients)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* Y, long ldy, int M, int N, float* out, int rows_per_block) {
@@ -2246,7 +2373,12 @@ extern "C" long osuf_gemm_tn_workspace_bytes(int dtype, int M, int N1, int N2, i
   int rows, sp;
   if (M <= 0 || N1 <= 0 || N2 <= 0 || taps <= 0 || !tn_big_plan(dtype, M, N1, N2, taps, &rows, &sp)) return 0;
   if ((N1 * (long)N2 * taps) % 4) return 0;
-  return (long)sp * taps * N1 * N2 * (long)sizeof(float);
+  return (long)sp * taps * N1 * N2 * (long)sizeof(float);            // (bf16-pair partial tiles need half of it; one size keeps callers simple)
+}
+// bf16 kernels write their partial tiles as bf16 pairs of rows (half the bytes of the write-out and of the reduce's reads); the fp32
+// modes keep fp32 tiles.  OSUF_WGRAD_F32_PARTIALS=1 restores fp32 tiles for A/B.
+static bool wgrad_pk(int dtype, int N1, int N2) {
+  return dtype == OSUF_DT_BF16 && (N1 % 2) == 0 && (N2 % 4) == 0 && getenv("OSUF_WGRAD_F32_PARTIALS") == nullptr;
 }
 
 extern "C" int osuf_colsum(int dtype, const void* Y, long ldy, int M, int N, float* out, hipStream_t stream);
@@ -2310,6 +2442,7 @@ static int gemm_tn_launch(int dtype, const void* dY, long ldy, const void* X, lo
     const bool dense = (out_layout == 1 && ((long)N1 * N2) % 4 == 0) || (out_layout == 0 && ldw == N2 && tapstride == (long)N1 * N2 && n % 4 == 0 && aligned16(dW));
     gb.ws = (workspace && dense && aligned16(workspace) && workspace_bytes >= (long)sp * n * (long)sizeof(float)) ? workspace : nullptr;
     gb.es = es;
+    gb.ws_pk = gb.ws && wgrad_pk(dtype, N1, N2);
     gb.dbias = dtype == OSUF_DT_BF16 ? dbias : nullptr;
     if (dtype != OSUF_DT_BF16) { if (int rc = bias_by_colsum()) return rc; }
     if (!gb.ws && !accumulate) (void)hipMemsetAsync(dW, 0, (size_t)n * sizeof(float), stream);    // atomic path needs zeros
@@ -2320,18 +2453,7 @@ static int gemm_tn_launch(int dtype, const void* dY, long ldy, const void* X, lo
     const dim3 grid_t3(((sp * btiles + 7) / 8) * 8);
     if (dtype == OSUF_DT_F32X3) hipLaunchKernelGGL(gemm_tn_taps3_x3_kernel, grid_t3, dim3(512), lds_t3, stream, gb);
     else hipLaunchKernelGGL(gemm_tn_taps3_kernel, grid_t3, dim3(512), lds_t3, stream, gb);
-    if (gb.ws) {
-      const long n12 = (long)N1 * N2;
-      const long groups = out_layout == 1 ? n12 / 4 : n / 4;
-      long blocks = (groups + 255) / 256;
-      if (blocks > 2048) blocks = 2048;
-      if (sp >= 8 && blocks < 512) {
-        const long b4 = (groups + 63) / 64;
-        if (out_layout == 1) hipLaunchKernelGGL(wgrad_reduce4_kernel<1>, dim3((int)b4), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
-        else hipLaunchKernelGGL(wgrad_reduce4_kernel<0>, dim3((int)b4), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
-      } else if (out_layout == 1) hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((int)blocks), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
-      else hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3((int)blocks), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
-    }
+    if (gb.ws) launch_wgrad_reduce(gb, dW, N1, N2, taps, sp, out_layout, accumulate, true, stream);
     return osuf_launch_status();
   }
   {
@@ -2346,6 +2468,7 @@ static int gemm_tn_launch(int dtype, const void* dY, long ldy, const void* X, lo
       const bool dense = (out_layout == 1 && ((long)N1 * N2) % 4 == 0) || (out_layout == 0 && ldw == N2 && (taps == 1 || tapstride == (long)N1 * N2) && n % 4 == 0 && aligned16(dW));
       gb.ws = (workspace && dense && aligned16(workspace) && workspace_bytes >= (long)sp * n * (long)sizeof(float)) ? workspace : nullptr;
       gb.es = es;
+      gb.ws_pk = gb.ws && wgrad_pk(dtype, N1, N2);
       gb.dbias = dtype == OSUF_DT_BF16 ? dbias : nullptr;
       if (dtype != OSUF_DT_BF16) { if (int rc = bias_by_colsum()) return rc; }
       if (!gb.ws && !accumulate) (void)hipMemsetAsync(dW, 0, (size_t)n * sizeof(float), stream);    // atomic path needs zeros
@@ -2359,18 +2482,7 @@ static int gemm_tn_launch(int dtype, const void* dY, long ldy, const void* X, lo
       }
       if (dtype == OSUF_DT_F32X3) hipLaunchKernelGGL(gemm_tn_big_x3_kernel, dim3(((sp * btiles + 7) / 8) * 8 * taps), dim3(512), lds_big, stream, gb);
       else hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(((sp * btiles + 7) / 8) * 8 * taps), dim3(512), lds_big, stream, gb);
-      if (gb.ws) {
-        const long n12 = (long)N1 * N2;
-        const long groups = out_layout == 1 ? n12 / 4 : n / 4;            // float4 output groups (x taps partial reads each in layout 1)
-        long blocks = (groups + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        if (sp >= 8 && blocks < 512 && (out_layout == 0 || taps == 3)) {   // many splits, few outputs: four split lanes per output group
-          const long b4 = (groups + 63) / 64;
-          if (out_layout == 1) hipLaunchKernelGGL(wgrad_reduce4_kernel<1>, dim3((int)b4), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
-          else hipLaunchKernelGGL(wgrad_reduce4_kernel<0>, dim3((int)b4), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
-        } else if (out_layout == 1) hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((int)blocks), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
-        else hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3((int)blocks), dim3(256), 0, stream, gb.ws, dW, n12, taps, sp, accumulate);
-      }
+      if (gb.ws) launch_wgrad_reduce(gb, dW, N1, N2, taps, sp, out_layout, accumulate, out_layout == 0 || taps == 3, stream);
       return osuf_launch_status();
     }
   }

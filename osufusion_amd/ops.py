@@ -60,6 +60,14 @@ def gemm_dt(t: torch.Tensor) -> int:
     return F32X3 if (t.dtype == torch.float32 and F32_MATMUL == "x3") else _DT[t.dtype]
 
 
+class LaunchSize(int):
+    """what a timed launch records: the sequence length N (as an int), with the launch's batch as .b"""
+    def __new__(cls, n, b=0):
+        x = int.__new__(cls, n)
+        x.b = b
+        return x
+
+
 class KernelTimer:
     """HIP-event timing of selected C-ABI launches on the stream they run on (bench.py's roofline leg)."""
 
@@ -426,7 +434,7 @@ def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.
     base, eo = qkv.data_ptr(), o.element_size()
     for g in range(G):
         call("osuf_mqa_fwd", base + 2 * g * r * D, ld, base + 2 * (H + g) * D, ld, base + 2 * (H + G + g) * D, ld, o.data_ptr() + eo * g * r * D,
-             H * D, _DT[out_dtype], lse.data_ptr() + 4 * g * B * r * N, B, r, N, D, scale, _stream(), meta=N)
+             H * D, _DT[out_dtype], lse.data_ptr() + 4 * g * B * r * N, B, r, N, D, scale, _stream(), meta=LaunchSize(N, B))
     return o, lse
 
 

@@ -188,7 +188,8 @@ def test_big_tile_gemm_kernel(monkeypatch, kind, k, L):
     res = torch.randn(B, Lout, Cout, device=DEV).to(torch.bfloat16)
     rscale = torch.rand(B, Cout, device=DEV)
     outs = []
-    for force in ("0", "1"):
+    monkeypatch.setenv("OSUF_WGRAD_F32_PARTIALS", "1")           # pin the kernel's products: fp32 partial tiles (the bf16-pair tiles of round 4 have
+    for force in ("0", "1"):                                     # their own test, tests/test_round4_gpu.py)
         monkeypatch.setenv("OSUF_GEMM_BIG_MIN_TILES", force)
         stats = torch.zeros(B, 2, dtype=torch.float64, device=DEV)
         y, pre = Fn.conv_forward(x, w, bias, Fn.PackCache(), kind, None, act=1, residual=res, rscale=rscale, stats=stats, want_pre=True)
@@ -196,6 +197,7 @@ def test_big_tile_gemm_kernel(monkeypatch, kind, k, L):
         dw = Fn.conv_wgrad(res, x, w, kind)                      # 256x256 LDS-DMA wgrad kernel when forced
         outs.append((y.float(), pre.float(), stats.clone(), dx.float(), dw.float()))
     monkeypatch.delenv("OSUF_GEMM_BIG_MIN_TILES")
+    monkeypatch.delenv("OSUF_WGRAD_F32_PARTIALS")
     (y0, p0, s0, d0, w0), (y1, p1, s1, d1, w1) = outs
     assert torch.equal(p0, p1)
     # y = silu(.)+res*rscale: the two kernels' epilogues are separate instantiations and may contract mul+add differently -- at most a
