@@ -10,7 +10,7 @@ import csv
 import json
 import sys
 
-ENTRY = {"mqa_fwd_kernel": "osuf_mqa_fwd", "mqa_bwd_fused_kernel": "osuf_mqa_bwd_fused", "mqa_bwd_fused512_kernel": "osuf_mqa_bwd_fused", "mqa_bwd_dq_pipe_kernel": "osuf_mqa_bwd_dq",
+ENTRY = {"mqa_fwd_kernel": "osuf_mqa_fwd", "mqa_bwd_fused_kernel": "osuf_mqa_bwd_fused", "mqa_bwd_fused512_kernel": "osuf_mqa_bwd_fused", "mqa_bwd_fused512a_kernel": "osuf_mqa_bwd_fused", "mqa_bwd_dq_pipe_kernel": "osuf_mqa_bwd_dq",
          "mqa_bwd_dq_kernel": "osuf_mqa_bwd_dq", "mqa_bwd_dkv_pipe_kernel": "osuf_mqa_bwd_dkv", "mqa_bwd_dkv_kernel": "osuf_mqa_bwd_dkv"}
 
 
