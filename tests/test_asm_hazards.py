@@ -1,6 +1,7 @@
 """hipcc pads no hazards around inline-asm MFMAs (cdna_hip_programming.md 5.7): the emitted code of the asm-MFMA kernel is linted instead.
 CPU-only (hipcc cross-compiles gfx950 without a GPU): compiles csrc/attn.hip with -save-temps and runs tools/check_mfma_hazards.py on
-both instantiations of mqa_bwd_fused512_kernel -- no VALU write of an MFMA source within two instructions, no compiler-generated
+both instantiations of mqa_bwd_fused512_kernel (the generated loop of mqa_bwd_fused512a_kernel has its own checks: tests/test_attn_bwd512_generator.py)
+-- no VALU write of an MFMA source within two instructions, no compiler-generated
 v_accvgpr_* and no scratch access inside the main loop (a reload there would wait for vmcnt(0), i.e. for the float atomics in flight)."""
 import shutil
 import subprocess
@@ -17,7 +18,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 @pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
 def test_asm_mfma_kernels_have_no_unpadded_hazards(tmp_path):
     src = ROOT / "osufusion_amd" / "csrc"
-    for f in ("attn.hip", "attn_generic.hpp", "common.hpp"):
+    for f in ("attn.hip", "attn_generic.hpp", "common.hpp", "attn_bwd512_asm.inc"):
         shutil.copy(src / f, tmp_path / f)
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-save-temps", "-c", "attn.hip",
                         "-o", "attn.o"], cwd=tmp_path, capture_output=True, text=True)

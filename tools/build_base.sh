@@ -6,7 +6,7 @@ cd /root/repo
 REV=${1:-HEAD}
 D=$(mktemp -d /tmp/osuf_base.XXXX)
 # every source the revision has (the list follows the tree, not this script: an omitted file means missing symbols at load time)
-for f in $(git ls-tree --name-only "$REV" osufusion_amd/csrc/ | grep -E "\.(hip|hpp)$" | xargs -n1 basename); do git show "$REV:osufusion_amd/csrc/$f" > "$D/$f"; done
+for f in $(git ls-tree --name-only "$REV" osufusion_amd/csrc/ | grep -E "\.(hip|hpp|inc)$" | xargs -n1 basename); do git show "$REV:osufusion_amd/csrc/$f" > "$D/$f"; done
 for f in $(cd "$D" && ls *.hip | sed s/.hip//); do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$D/$f.hip" -o "$D/$f.o" &
 done
