@@ -264,9 +264,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
     __syncthreads();
   };
   const bool ragged = (a.N & 63) != 0;
-  for (int j = 0; j < ntiles - 1; ++j) tile(j, std::false_type{});
+  const int nfull = ragged ? ntiles - 1 : ntiles;                   // one unmasked copy of the tile body: with a loop AND a peeled unmasked twin
+  for (int j = 0; j < nfull; ++j) tile(j, std::false_type{});      // hipcc spilled 200 B per lane around the twins (round 4: 128 -> 122 VGPRs, no scratch)
   if (ragged) tile(ntiles - 1, std::true_type{});
-  else tile(ntiles - 1, std::false_type{});
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (qok) {
     const float inv = 1.f / l_tot;
