@@ -364,7 +364,9 @@ def adapter_grads(ad: Adapter, dy, x, y, bias, kind: str, cache: PackCache, sums
         sg, pbt = ad.sg, ad.sgbt[dt]                                                               # [1][r][O]
         u = ops.gemm_nt(x, pa, None, taps=k, lin=Lin, lout=Lout, stride=stride, pad=pad, mode=mode, out_shape=(B_, Lout, r))
         du = ops.gemm_nt(dy, pbt, None, out_shape=(B_, Lout, r))
-        tb = ops.gemm_tn(dy, u, n1=O)                                                              # [1][O][r] = dy^T u
+        # (outputs of the skinny weight-gradient kernel: fp32 atomics into zeros.  Taken from the step's accumulator arena and added into
+        #  -- one fill per step instead of a hipMemsetAsync per call: 360 ten-microsecond fills per DoRA step went that way)
+        tb = ops.gemm_tn(dy, u, n1=O, out=ops.zeros((1, O, r), torch.float32, x.device), accumulate=True)   # [1][O][r] = dy^T u
         s0 = s1 = None
         if ad.m is not None:
             if sums is not None:                           # (sum dy*y, sum dy) already produced by the GroupNorm backward
@@ -376,7 +378,8 @@ def adapter_grads(ad: Adapter, dy, x, y, bias, kind: str, cache: PackCache, sums
         if kind == "same":
             # dA^T instead of dA, so that the rank-r operand is the SECOND one (the skinny wgrad kernel wants N2 = r):
             #   G[t'][i][q] = sum_m' x[m'][i] du[m' + t' - (k-1-pad)][q]  ==  dA[q][i][k-1-t']      (same set of (row, tap) pairs)
-            gt = ops.gemm_tn(x, du, taps=k, lin=Lin, lout=Lout, stride=1, pad=k - 1 - pad, mode=0, n1=I)
+            gt = ops.gemm_tn(x, du, taps=k, lin=Lin, lout=Lout, stride=1, pad=k - 1 - pad, mode=0, n1=I,
+                             out=ops.zeros((k, I, r), torch.float32, x.device), accumulate=True)
             # one kernel scales dB, un-flips / transposes dA and finishes dm -- straight into the parameters' .grad when the
             # Trainer's flat gradient buffer is in use
             tgt = [grad_target(ad.a), grad_target(ad.b)] + ([grad_target(ad.m)] if ad.m is not None else [])
@@ -650,8 +653,8 @@ class BlockFn(torch.autograd.Function):
                 db = tbias = torch.zeros(bias.shape, dtype=torch.float32, device=dh.device)
         want_dm = ad is not None and ad.m is not None and need[10]
         if want_dm:                                        # DoRA magnitude: column sums of dy*y and of dy, same closed form
-            dyy = torch.zeros(y.shape[-1], dtype=torch.float32, device=dh.device)
-            sdy = tbias if db is not None else torch.zeros(y.shape[-1], dtype=torch.float32, device=dh.device)
+            dyy = ops.zeros((y.shape[-1],), torch.float32, dh.device)
+            sdy = tbias if db is not None else ops.zeros((y.shape[-1],), torch.float32, dh.device)
         dy, dgamma, dbeta, dss = ops.gn_bwd(_rc(dh), y, mr, gamma, beta, ss, L, tg if direct_norm else None, tb if direct_norm else None,
                                             sdy if want_dm else tbias, dyy, identity_norm=ctx.identity_norm)
         if tbias is not None and db is None:

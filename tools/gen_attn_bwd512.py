@@ -284,7 +284,15 @@ def dq_mma(e, first):
     e.mfma16(ACC1, DQA1, DQB, first)
 
 
+PKC, PKDS = "--pkc" in sys.argv, "--pkds" in sys.argv          # packed forms of the two elementwise products (two per instruction; same fp32 results)
+SC2 = 92                                                         # s[92:93] = (c, c) for the packed form
+
+
 def mul_exp(e, r):
+    if PKC:
+        if r % 2 == 0:
+            e.valu(f"v_pk_mul_f32 {vr(S + r, 2)}, {vr(S + r, 2)}, s[{SC2}:{SC2 + 1}]", vset(S + r, 2), vset(S + r, 2))
+        return
     e.valu(f"v_mul_f32_e32 {vr(S + r)}, s{SC}, {vr(S + r)}", vset(S + r), vset(S + r))
 
 
@@ -297,6 +305,10 @@ def cvt(e, dst, src):
 
 
 def ds_mul(e, r):
+    if PKDS:
+        if r % 2 == 0:
+            e.valu(f"v_pk_mul_f32 {vr(DP + r, 2)}, {vr(S + r, 2)}, {vr(DP + r, 2)}", vset(S + r, 2) | vset(DP + r, 2), vset(DP + r, 2))
+        return
     e.valu(f"v_mul_f32_e32 {vr(DP + r)}, {vr(S + r)}, {vr(DP + r)}", vset(S + r) | vset(DP + r), vset(DP + r))
 
 
@@ -779,6 +791,8 @@ def generate():
     e.salu(f"s_cselect_b32 s{SHS}, 0, s{SHS}")
     e.salu(f"s_mov_b32 s{SMASK}, -1")
     e.salu(f"s_mov_b32 s{SMASK + 1}, 0")
+    e.salu(f"s_mov_b32 s{SC2}, s{SC}")
+    e.salu(f"s_mov_b32 s{SC2 + 1}, s{SC}")
     # The loop's text must be valid for the state the back edge arrives in (MFMA results of the previous iteration still settling), which
     # needs at least the padding of the first entry: emit the two bodies from the post-iteration state until the text repeats.
     import copy
@@ -851,7 +865,7 @@ def main():
             f.write(f'  "{l}\\n\\t" \\\n')
         f.write('  ""\n')
         cl = ", ".join(f'"v{i}"' for i in range(64, 192)) + ", " + ", ".join(f'"a{i}"' for i in range(256))
-        sc = ", ".join(f'"s{i}"' for i in (SD128, SDN4, SDQS, SHS, SHD, SMASK, SMASK + 1) + tuple(range(SROW, SROW + 8)))
+        sc = ", ".join(f'"s{i}"' for i in (SD128, SDN4, SDQS, SHS, SHD, SMASK, SMASK + 1) + tuple(range(SROW, SROW + 8)) + (SC2, SC2 + 1))
         f.write(f'#define OSUF_BWD512A_CLOBBERS "memory", "vcc", "scc", {sc}, {cl}\n')
     if "--stats" in sys.argv:
         per_pair = {k: v / 2 for k, v in loop_count.items() if k not in ("init", "fini")}
