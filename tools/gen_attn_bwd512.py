@@ -16,8 +16,13 @@ order of every accumulation, so dK / dV come out bit-identical -- is emitted as 
   * s_waitcnt lgkmcnt(N) / s_nop are inserted by this script from a model of the in-order LDS queue and of the MFMA result latencies
     (cdna_hip_programming.md 5.7: hipcc pads nothing around an asm statement).
 
-Output: osufusion_amd/csrc/attn_bwd512_asm.inc (macros OSUF_BWD512A_ASM / _CLOBBERS; the register map is shared with the C++ side through
-the constants printed at its top).   usage: python tools/gen_attn_bwd512.py [--stats]
+  * the list-scheduled body is checked against the hand-ordered one (--manual; pinned on the GPU bit for bit against the compiled kernel) by
+    symbolic execution: same value in every register after four iterations, same LDS stores / atomics / DMA requests.
+
+Output: osufusion_amd/csrc/attn_bwd512_asm.inc (macros OSUF_BWD512A_ASM / _CLOBBERS; the C++ side binds its operands to the physical registers of
+the map below).   usage: python tools/gen_attn_bwd512.py [--stats] [--gaps] [--manual]
+Triage / tuning knobs (timing-only or A/B builds through tools/build_variants.sh): --drop valu,atomics,dq,dqreads,lds,barrier,dma,vmwait,atomstore
+--pad N --padlds --e64 --pkc --pkds --lat N --ldscap B,S --budget B,S --look N --ksp N --cwlate --out FILE
 """
 from __future__ import annotations
 
@@ -40,7 +45,6 @@ DQB, DQA0, DQA1, ACC0, ACC1 = 192, 196, 200, 204, 208
 CS = 212                          # -lse / c of the pair's 32 queries as this lane's accumulator rows: the C operand of every S chain's first MFMA
 AO, CL, CD = 228, 230, 231        # byte offsets of the atomics of the two query halves (rows: scalar bases); row constants of the next stage in flight
 RK, T, KO, EO, EW, CR, CW, QOFF, DOOFF, COFF, RTMP = 232, 236, 240, 242, 246, 250, 251, 252, 253, 254, 255
-TMP0, TMP1 = S, S + 1             # (scratch of the stage's row constants: S is dead between the last tile's dS and the next pair)
 # AGPRs: dK^T tile t, head-dim half dt at a[32 t + 16 dt ..+15]; dV^T at a[128 + 32 t + 16 dt ..]
 def DK(t, dt): return 32 * t + 16 * dt
 def DV(t, dt): return 128 + 32 * t + 16 * dt
@@ -50,7 +54,7 @@ SCNT, SH, SHS, SREM, SHD, SN4 = 60, 61, 62, 63, 64, 65          # loop trips, he
 SWQ, SWDO, SWLS, SWDQ = 66, 68, 70, 72                         # wrap deltas (bytes, low words used) at the last head of a query block
 SD128, SDN4, SDQS = 58, 59, 90                                 # per-head steps of QOFF / DOOFF, of COFF, of AO (0 once past the last pair / in the first iteration)
 SC, SNRC, SM0, SKOF, SMASK = 74, 75, 76, 77, 78                  # c = scale log2 e, -1/c, LDS byte address of this wave's 1-KiB DMA piece, RK - RS, lane mask (pair)
-SROWB, SROW = 80, 82                                             # bytes per dQ row; s[82:89]... rows 0..3 of the part's first pair: s[82:83] .. s[88:89]
+SROWB, SROW = 80, 82                                             # bytes per dQ row; s[82:89]: scalar bases of dQ rows 0..3 of the part's first pair
 # LDS map (bytes): [2 x (Q 4096 | dO 4096 | -lse/c 128 | -delta 128)] | K image 65536 | 2 x dS image 32768
 STAGE, KIMG, EIMG = 8448, 16896, 82432
 
@@ -337,17 +341,6 @@ def spread(spine, fillers):
         m()
         for f in fl:
             f()
-
-
-def chunks(lst, n):
-    """lst cut into n consecutive pieces, sizes as even as possible"""
-    k, r = divmod(len(lst), n)
-    out, i = [], 0
-    for j in range(n):
-        sz = k + (1 if j < r else 0)
-        out.append(lst[i:i + sz])
-        i += sz
-    return out
 
 
 def merge(*gaplists):
