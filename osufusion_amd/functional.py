@@ -48,36 +48,28 @@ class PackCache:
         if hit is not None and hit[0] == ver:
             if hit[2] is not None:
                 hit[2].used = True
-                _wait_side(hit[2])
             return hit[1]
         ws = weights if isinstance(weights, (tuple, list)) else (weights,)
         with torch.no_grad():
-            pair = _build_pair(ws, kind, dt)
+            if len(ws) == 1:
+                pair = _pack_one(ws[0], dt, kind)
+            else:
+                I = ws[0].shape[1]
+                total = sum(w.shape[0] for w in ws)
+                dev = ws[0].device
+                fwd = torch.empty((1, total, I), dtype=dt, device=dev)
+                dgr = torch.empty((1, I, total), dtype=dt, device=dev)
+                off = 0
+                for w in ws:
+                    _pack_one(w, dt, kind, fwd=fwd, dgrad=dgr, row_offset=off)
+                    off += w.shape[0]
+                pair = (fwd, dgr)
         job = None
         if all(_plain_master(w, params) for w in ws):
             job = _PackJob(self, key, tuple(params), tuple(ws), kind, dt, pair)
             _PACK_JOBS[(id(self), key)] = job
-        elif any(isinstance(w, EffWeight) for w in ws):
-            job = _AdapterJob(self, key, tuple(params), tuple(ws), kind, dt)     # re-built ahead of its next use by refresh_adapters()
-            _ADAPTER_JOBS[(id(self), key)] = job
         self._d[key] = (ver, pair, job)
         return pair
-
-
-def _build_pair(ws, kind: str, dt: torch.dtype):
-    """(fwd, dgrad) GEMM operands of one weight, or of several stacked along O (the fused q|kv projection)"""
-    if len(ws) == 1:
-        return _pack_one(ws[0], dt, kind)
-    I = ws[0].shape[1]
-    total = sum(w.shape[0] for w in ws)
-    dev = ws[0].device
-    fwd = torch.empty((1, total, I), dtype=dt, device=dev)
-    dgr = torch.empty((1, I, total), dtype=dt, device=dev)
-    off = 0
-    for w in ws:
-        _pack_one(w, dt, kind, fwd=fwd, dgrad=dgr, row_offset=off)
-        off += w.shape[0]
-    return fwd, dgr
 
 
 def _plain_master(w, params=()) -> bool:
@@ -139,71 +131,6 @@ def refresh_packs() -> int:
                 j.used = False
             done += len(jobs)
     return done
-
-
-class _AdapterJob:
-    """A cached pack that contains an adapter's effective weight: re-built after every optimizer step, on a side stream."""
-    __slots__ = ("cache", "key", "params", "ws", "kind", "dt", "used", "event")
-
-    def __init__(self, cache, key, params, ws, kind, dt) -> None:
-        self.cache, self.key, self.params, self.ws, self.kind, self.dt = weakref.ref(cache), key, params, ws, kind, dt
-        self.used, self.event = True, None
-
-
-_ADAPTER_JOBS: Dict[Tuple, _AdapterJob] = {}          # in first-use (= forward) order
-_SIDE_STREAM: Dict[str, torch.cuda.Stream] = {}
-
-
-def _wait_side(obj) -> None:
-    """first use, on the current stream, of something refresh_adapters() built on the side stream"""
-    ev = getattr(obj, "event", None)
-    if ev is not None:
-        torch.cuda.current_stream().wait_event(ev)
-        obj.event = None
-
-
-def refresh_adapters() -> int:
-    """LoRA / DoRA step: every adapter's gain and effective-weight packs go stale with the optimizer step -- ~5 ten-microsecond kernels per
-    adapted layer (dora_sumsq, dora_gain, the s g product, the adapted pack), 180 layers: 7 ms per step when each layer rebuilt its own in the
-    forward.  Here they are re-built right after the optimizer step on a SIDE stream, in the order in which the forward will ask for them,
-    each with an event that its first user waits for: the small kernels run beside the first big GEMMs of the next forward instead of
-    between them.  (The side stream first waits for the main stream: the optimizer's update, and every kernel that still reads the old packs.)
-    -> number of packs rebuilt."""
-    jobs = []
-    for k, job in list(_ADAPTER_JOBS.items()):
-        cache = job.cache()
-        ent = cache._d.get(job.key) if cache is not None else None
-        if ent is None or ent[2] is not job:
-            del _ADAPTER_JOBS[k]
-            continue
-        if job.used:
-            jobs.append(job)
-    if not jobs:
-        return 0
-    main = torch.cuda.current_stream()
-    dev = str(jobs[0].params[0].device)
-    side = _SIDE_STREAM.get(dev)
-    if side is None:
-        side = _SIDE_STREAM[dev] = torch.cuda.Stream(device=jobs[0].params[0].device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side), torch.no_grad():
-        for job in jobs:
-            ws = []
-            for w in job.ws:
-                if isinstance(w, EffWeight):
-                    eff, _ = w.ad.effective()                     # new gain for the updated factors (launched on the side stream)
-                    ws.append(eff)
-                else:
-                    ws.append(w)
-            pair = _build_pair(ws, job.kind, job.dt)
-            ev = side.record_event()
-            for w in ws:
-                if isinstance(w, EffWeight):
-                    w.ad.event = ev                               # backward users of g / (s g B)^T wait for it too
-            job.ws, job.event, job.used = tuple(ws), ev, False
-            ver = (_WEIGHT_EPOCH, *[(p._version, p.data_ptr()) for p in job.params])
-            job.cache()._d[job.key] = (ver, pair, job)
-    return len(jobs)
 
 
 def _pack_one(w, dt, kind, **kw):
@@ -398,7 +325,6 @@ class Adapter:
     def __init__(self, base_weight, lora_a, lora_b, magnitude, scaling: float) -> None:
         self.w, self.a, self.b, self.m, self.scaling = base_weight, lora_a, lora_b, magnitude, float(scaling)
         self._eff = None
-        self.event = None                                    # set by refresh_adapters(): the gain was rebuilt on the side stream
 
     @property
     def params(self) -> Tuple[torch.Tensor, ...]:
@@ -415,9 +341,6 @@ class Adapter:
                 self.sg = g * self.scaling
                 self.sgbt = {torch.float32: t32, torch.bfloat16: t16}          # (s g B)^T, the operand of du = dy (s g B)
             self._eff = (ver, EffWeight(self, g), g)
-            self.event = None
-        else:
-            _wait_side(self)
         return self._eff[1], self._eff[2]
 
 

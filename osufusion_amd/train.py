@@ -377,7 +377,6 @@ class Trainer:
             self._reorder_pending = False
             self.apply_observed_order()
         Fn.refresh_packs()                                  # every packed GEMM operand went stale with that step: one grouped launch
-        Fn.refresh_adapters()                               # ... and the adapters' gains / effective-weight packs: side stream, ahead of their use
         return loss.detach(), total_norm
 
     def apply_observed_order(self) -> None:
