@@ -101,7 +101,11 @@ __device__ __forceinline__ void store_grad(void* base, long ld, long m, int col0
   else store_grad_row(reinterpret_cast<float*>(base) + m * ld + col0, acc, mul, cs, sn, lh);
 }
 
+#ifdef OSUF_FWD_TRIAGE_NOEXP
+__device__ __forceinline__ float fast_exp2(float x) { return x * 0.001f; }     // timing-only triage builds (tools/build_fwd_triage.sh): never in the product
+#else
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#endif
 
 struct AttnArgs {
   const bf16_t* q; const bf16_t* k; const bf16_t* v;
@@ -200,7 +204,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
     constexpr bool MASK = decltype(mask_tag)::value;
     const char* ks_ = smem + (j & 1) * 16384;
     const char* vs_ = ks_ + 8192;
+#ifndef OSUF_FWD_TRIAGE_NOLOAD
     if (j + 1 < ntiles) st.load(a, b, (j + 1) * 64, tid);
+#endif
     // S^T = K Q^T  (two 32-key tiles)
     f32x16 s[2];
 #pragma unroll
@@ -260,8 +266,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
       for (int dt = 0; dt < 2; ++dt)
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(vs_, lo, (s4 >> 1) * 32 + (s4 & 1) * 16, dt), pf, o[dt], 0, 0, 0);
     }
+#ifndef OSUF_FWD_TRIAGE_NOLOAD
     if (j + 1 < ntiles) st.store(smem + ((j + 1) & 1) * 16384, smem + ((j + 1) & 1) * 16384 + 8192, tid);
+#endif
+#ifndef OSUF_FWD_TRIAGE_NOBARRIER
     __syncthreads();
+#endif
   };
   const bool ragged = (a.N & 63) != 0;
   const int nfull = ragged ? ntiles - 1 : ntiles;                   // one unmasked copy of the tile body: with a loop AND a peeled unmasked twin
