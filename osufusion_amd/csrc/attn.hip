@@ -247,6 +247,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
     }
+    // (the packed forms v_pk_fma_f32 / v_pk_add_f32 of these two elementwise streams were measured 4 % SLOWER: N = 8192 9.36 -> 9.75 ms)
     float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
