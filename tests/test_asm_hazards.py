@@ -28,3 +28,11 @@ def test_asm_mfma_kernels_have_no_unpadded_hazards(tmp_path):
         lint = subprocess.run([sys.executable, str(ROOT / "tools" / "check_mfma_hazards.py"), inst, str(asm)], capture_output=True, text=True)
         assert lint.returncode == 0, lint.stdout[-3000:]
         assert "128 MFMAs checked, 0 finding(s)" in lint.stdout, lint.stdout[-500:]
+    # the forward kernel keeps its four waves per SIMD (<= 128 VGPRs) WITHOUT scratch since round 4 (one unmasked copy of the tile body);
+    # the generated backward loop runs at one wave per SIMD on the whole register file, also without scratch traffic in its loop
+    import re
+    text = asm.read_text()
+    for sym, max_scratch in (("_Z14mqa_fwd_kernelILi8EEv8AttnArgs", 0),):
+        m = re.search(re.escape(sym) + r":.*?; NumVgprs: (\d+).*?; ScratchSize: (\d+)", text, re.S)
+        assert m, sym
+        assert int(m.group(1)) <= 128 and int(m.group(2)) <= max_scratch, (sym, m.group(1), m.group(2))
