@@ -26,6 +26,37 @@ def main():
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     body = [l.strip() for l in lines[start:end] if l.strip() and not l.strip().startswith((";", "."))]
     bad = 0
+    # Round 4: the fences BEHIND the asm MFMAs are checked too -- a non-MFMA instruction (or an MFMA through its A / B operand)
+    # that touches a register an MFMA wrote needs 12 wait states behind a 32x32x16 and 8 behind a 16x16x32 (same rule as check_inc below)
+    ws, ready, shape = 0, {}, {}
+    for l in body:
+        op, _, rest = l.partition(" ")
+        toks = [t.strip() for t in rest.split(",")] if rest else []
+        if op == "s_nop":
+            ws += int(toks[0]) + 1 if toks and toks[0].isdigit() else 1
+            continue
+        if op.startswith("v_mfma"):
+            big = "32x32" in op
+            dst = regs(toks[0])
+            for t in toks[1:3]:
+                for r in regs(t):
+                    if ready.get(r, 0) > ws:
+                        print(f"HAZARD: MFMA operand {r} read {ready[r] - ws} wait state(s) before its MFMA result is written back: {l}"); bad += 1
+            c = regs(toks[3]) if len(toks) > 3 else set()
+            for r in c:
+                if ready.get(r, 0) > ws and not (c == dst and shape.get(r) == big):
+                    print(f"HAZARD: MFMA C operand {r} from an MFMA of another shape / register: {l}"); bad += 1
+            ws += 1
+            for r in dst:
+                ready[r] = ws + (12 if big else 8)
+                shape[r] = big
+            continue
+        if op.startswith(("v_", "ds_", "global_", "scratch_", "buffer_")):
+            for t in toks:
+                for r in regs(t.split(" ")[0]):
+                    if ready.get(r, 0) > ws:
+                        print(f"HAZARD: {op} touches {r} {ready[r] - ws} wait state(s) before its MFMA result is written back: {l}"); bad += 1
+        ws += 1                                             # (straight-line scan: the fall-through of every branch is checked with everything in flight)
     hist = []                                               # (op, written regs, is_valu, nop states)
     for l in body:
         op, _, rest = l.partition(" ")
