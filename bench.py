@@ -48,6 +48,18 @@ def pmc_traffic(kernel: str):
     return (row["bytes_per_launch"], row.get("source")) if row else (None, None)
 
 
+def pmc_mfma_busy():
+    """MFMA-busy share of the attention-backward sweep over a train step (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1,024 SIMDs)) from the
+    committed counter pass (profiles/r04_pmc_t/mfma_busy.txt, tools/pmc_mfma.py); None when the file has no row for it."""
+    try:
+        for line in (ROOT / "profiles" / "r04_pmc_t" / "mfma_busy.txt").read_text().splitlines():
+            if line.startswith("mqa_bwd_fused512a_kernel"):
+                return round(float(line.split("%")[0].split()[-1]) / 100.0, 4)
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
 def synth_batch(rank: int, device, batch: int, length: int):
     """SURVEY section 8d synthetic inputs, generated once and resident in HBM before the timed region."""
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -306,6 +318,7 @@ def main() -> None:
                         frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4), traffic=traffic, traffic_unit="HBM-side bytes per launch", traffic_source=tsrc,
                         flops="algorithmic (SURVEY 8d: attention backward = 2 x forward, recomputed products not counted)",
                         executed=round(exe, 1), executed_frac=round(exe / MFMA_BF16_PEAK_TFLOPS, 4), launches=stats[dom]["launches"],
+                        mfma_busy=pmc_mfma_busy() if (full and dom == "osuf_mqa_bwd_fused") else None,
                         mean_launch_ms=round(stats[dom]["total_ms"] / stats[dom]["launches"], 3),
                         attention_backward=dict(kernels=bwd, ms_per_step=round(bwd_ms / args.steps, 2),
                                                 achieved=round(sum(tflop(k, 0) for k in bwd) / (bwd_ms / 1e3), 1) if bwd_ms else None),
