@@ -33,31 +33,49 @@ STEP_TFLOP = 125.1                      # 3 x 1,303 GFLOP/sample x 32 (SURVEY.md
 # backward as 2x the forward (recompute is not work): forward 4; the dQ kernel and the dK/dV kernel 4 + 4 (they EXECUTE 6 + 8: S
 # and dP are recomputed in both); the fused backward sweep is the whole backward, 8 (it executes 10: five products).
 ATTN_UNITS = {"osuf_mqa_fwd": (4.0, 4.0), "osuf_mqa_bwd_dq": (4.0, 6.0), "osuf_mqa_bwd_dkv": (4.0, 8.0), "osuf_mqa_bwd_fused": (8.0, 10.0)}
-TRAFFIC_FILE = ROOT / "profiles" / "attn_hbm_traffic.json"   # HBM-side bytes per launch from rocprofv3 --pmc passes (tools/pmc_traffic.py)
+PMC_MANIFEST = ROOT / "profiles" / "pmc_manifest.json"    # which committed counter summaries to quote + the kernel-source hash they were taken on
+
+
+def pmc_manifest():
+    """The committed counter summaries (tools/pmc_manifest.py) -- or (None, why) when the attention kernel sources of this tree are not
+    the ones those counters were collected on: bench.py cannot run the profiler on itself, so it must not quote stale counters."""
+    try:
+        man = json.loads(PMC_MANIFEST.read_text())
+        from osufusion_amd.csrc.build import source_hash
+        now = source_hash(man["attn_sources"])
+    except (OSError, ValueError, KeyError) as e:
+        return None, f"no usable profiles/pmc_manifest.json ({type(e).__name__})"
+    if now != man["attn_source_sha256"]:
+        return None, f"stale: attention kernel sources changed since the counter passes of tree {man.get('tree')} (no new PMC pass committed)"
+    return man, None
 
 
 def pmc_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` (mean over one step's launches at the headline shape) from the committed counter summary:
-    separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md 'HBM' prescribes.  bench.py cannot run the
-    profiler on itself; None when the summary has no row for the kernel that dominates this run."""
+    """(HBM bytes per launch of `kernel`, source tag): mean over one step's launches at the headline shape, separate FETCH_SIZE /
+    WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md 'HBM' prescribes.  (None, reason) when stale or absent."""
+    man, why = pmc_manifest()
+    if man is None:
+        return None, why
     try:
-        rows = json.loads(TRAFFIC_FILE.read_text())
+        row = json.loads((ROOT / man["traffic"]).read_text()).get(kernel)
     except (OSError, ValueError):
-        return None, None
-    row = rows.get(kernel)
-    return (row["bytes_per_launch"], row.get("source")) if row else (None, None)
+        return None, f"{man['traffic']} unreadable"
+    return (row["bytes_per_launch"], f"{row.get('source')} [tree {man.get('tree')}]") if row else (None, f"no row for {kernel} in {man['traffic']}")
 
 
 def pmc_mfma_busy():
-    """MFMA-busy share of the attention-backward sweep over a train step (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1,024 SIMDs)) from the
-    committed counter pass (profiles/r04_pmc_t/mfma_busy.txt, tools/pmc_mfma.py); None when the file has no row for it."""
+    """(MFMA-busy share of the attention-backward sweep over a train step, source): SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1,024
+    SIMDs) from the committed counter pass (tools/pmc_mfma.py).  (None, reason) when stale or absent."""
+    man, why = pmc_manifest()
+    if man is None:
+        return None, why
     try:
-        for line in (ROOT / "profiles" / "r04_pmc_t" / "mfma_busy.txt").read_text().splitlines():
+        for line in (ROOT / man["mfma_busy"]).read_text().splitlines():
             if line.startswith("mqa_bwd_fused512a_kernel"):
-                return round(float(line.split("%")[0].split()[-1]) / 100.0, 4)
+                return round(float(line.split("%")[0].split()[-1]) / 100.0, 4), f"{man['mfma_busy']} [tree {man.get('tree')}]"
     except (OSError, ValueError, IndexError):
         pass
-    return None
+    return None, f"no mqa_bwd_fused512a_kernel row in {man['mfma_busy']}"
 
 
 def synth_batch(rank: int, device, batch: int, length: int):
@@ -80,9 +98,17 @@ def build_model(device, dim_h: int):
     return model.to(device)
 
 
-def cpu_baseline(model, length: int, threads: int):
+def cpu_baseline(model, length: int, thread_counts):
     """The oracle (CPU restatement of the reference, pinned to its golden vectors) on this box's host cores: one fwd+bwd
-    of the same full-size model at B=1, L=length, fp32 params + bf16 SDPA exactly as the reference computes on CPU."""
+    of the same full-size model at B=1, L=length, fp32 params + bf16 SDPA exactly as the reference computes on CPU.  Timed at
+    every thread count given; `value` is the FASTEST of them (the CPU's best), the others are listed under `other_thread_counts`."""
+    runs = [_cpu_baseline_at(model, length, n, warm=3 if i == 0 else 1, timed=5 if i == 0 else 3) for i, n in enumerate(thread_counts)]
+    best = max(runs, key=lambda r: r["value"])
+    best["other_thread_counts"] = [dict(cores=r["cores"], value=r["value"], sample=r["sample"]) for r in runs if r is not best]
+    return best
+
+
+def _cpu_baseline_at(model, length: int, threads: int, warm: int = 3, timed: int = 5):
     from oracle import diffusion_oracle as DO
     from oracle import unet_oracle as O
     torch.set_num_threads(threads)
@@ -91,7 +117,7 @@ def cpu_baseline(model, length: int, threads: int):
     p = {k: v.detach().float().cpu().clone().requires_grad_() for k, v in model.state_dict().items()}
     x, a, c, noise, t = synth_batch(0, "cpu", 1, length)
     times = []
-    warm, timed = 3, 5                                     # 3 warm-ups, 5 timed iterations, median (~25 s of CPU work)
+    # 3 warm-ups, 5 timed iterations, median (~25 s of CPU work) at the first thread count
     for it in range(warm + timed):
         for v in p.values():
             v.grad = None
@@ -145,17 +171,19 @@ def sampler_secondary(model, device):
     if st:
         tfl = sum(4.0 * n.b * HEADS * int(n) * int(n) * HEAD_DIM for n in st["sizes"]) / 1e12
         ach = tfl / (st["total_ms"] / 1e3)
-        pmc = {}
-        try:
-            pmc = json.loads((ROOT / "profiles" / "r04_pmc_sampler" / "summary.json").read_text())["kernels"].get("mqa_fwd_kernel<8>", {})
-        except (OSError, ValueError, KeyError):
-            pass
+        pmc, (man, why) = {}, pmc_manifest()
+        if man is not None:
+            try:
+                pmc = json.loads((ROOT / man["sampler"]).read_text())["kernels"].get("mqa_fwd_kernel<8>", {})
+                why = f"{man['sampler']} [tree {man.get('tree')}] (rocprofv3 --pmc passes over tools/sampler_short.py, S = 3)"
+            except (OSError, ValueError, KeyError):
+                why = f"{man['sampler']} unreadable"
         traffic = (pmc.get("fetch_bytes_x2_per_launch", 0) + pmc.get("write_bytes_per_launch", 0)) or None
         roof = dict(bound="mfma", kernel="osuf_mqa_fwd", achieved=round(ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     launches=st["launches"], mean_launch_ms=round(st["total_ms"] / st["launches"], 3), share_of_sample=round(st["total_ms"] / 1e3 / dt, 3),
                     traffic=traffic, traffic_unit="HBM-side bytes per launch (mean over the sampler's launches, N = 8192 .. 1024)",
                     mfma_busy=pmc.get("mfma_busy"), scratch_bytes_per_lane=pmc.get("scratch_bytes_per_lane"),
-                    traffic_source="profiles/r04_pmc_sampler/summary.json (rocprofv3 --pmc passes over tools/sampler_short.py, S = 3)")
+                    traffic_source=why)
     return dict(metric=f"DDIM sampling steps/sec at B={SAMPLER_B} L={SAMPLER_L} S={SAMPLER_S} cond_scale={SAMPLER_CFG} (BASELINE config 4), 1 MI355X",
                 sampling_steps_per_s=round(SAMPLER_S / dt, 3), seconds=round(dt, 3), samples_per_s=round(SAMPLER_B / dt, 3), dtype="bf16",
                 pflop=round(SAMPLER_PFLOP, 3), frac_of_peak=round(SAMPLER_PFLOP * 1e3 / dt / MFMA_BF16_PEAK_TFLOPS, 4),
@@ -203,13 +231,28 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def host_threads() -> int:
-    """Threads for the CPU baseline: this process's CPU affinity, capped at the 16-thread share of a 1-GPU box."""
+def physical_cores_in_affinity() -> int:
+    """Physical cores this process may run on (`torch.set_num_threads(<physical cores>)`): distinct
+    (package, core) pairs of the CPUs in the affinity mask; the mask size itself when sysfs has no topology."""
     try:
-        n = len(os.sched_getaffinity(0))
+        cpus = sorted(os.sched_getaffinity(0))
     except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(n, 16))
+        return os.cpu_count() or 1
+    cores = set()
+    for c in cpus:
+        try:
+            base = Path(f"/sys/devices/system/cpu/cpu{c}/topology")
+            cores.add(((base / "physical_package_id").read_text().strip(), (base / "core_id").read_text().strip()))
+        except OSError:
+            return len(cpus)
+    return max(1, len(cores))
+
+
+def host_thread_counts():
+    """Thread counts the CPU baseline is timed at: every physical core of the affinity mask, and the
+    16-thread share a 1-GPU box of the pool is entitled to (a cgroup quota, where there is one, makes the smaller count the faster)."""
+    n = physical_cores_in_affinity()
+    return sorted({n, min(n, 16)}, reverse=True)
 
 
 def main() -> None:
@@ -297,6 +340,31 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
 
+    comm = None
+    if world > 1:
+        # what a first multi-GPU run needs to diagnose itself: what the reducer did in the last timed step on this rank, the same over
+        # all ranks, and the gradient all-reduce ALONE (all buckets back to back on an idle GPU: the xGMI-bound part of a step)
+        comm = trainer.comm_stats()
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {k: comm[k] for k in ("buckets_fired_before_finish", "out_of_order_completions", "finish_wait_ms",
+                                                                "order_disagreements", "layout_fingerprint", "allreduce_bytes")})
+        red = trainer.reducer
+        alone = []
+        for _ in range(3):
+            sync()
+            t1 = time.perf_counter()
+            hs = [dist.all_reduce(trainer.flat.grad[s0:e0], op=dist.ReduceOp.SUM, async_op=True) for s0, e0 in red.bounds]
+            for h in hs:
+                h.wait()
+            torch.cuda.synchronize()
+            alone.append(time.perf_counter() - t1)
+        alone_t = torch.tensor([min(alone)], dtype=torch.float64, device=device)
+        dist.all_reduce(alone_t, op=dist.ReduceOp.MAX)
+        nbytes = trainer.flat.grad.numel() * trainer.flat.grad.element_size()
+        comm.update(per_rank=per_rank, devices_visible=torch.cuda.device_count(), device=torch.cuda.get_device_name(device),
+                    allreduce_alone_ms=round(1e3 * alone_t.item(), 3),
+                    allreduce_alone_busbw_gbs=round(2 * (world - 1) / world * nbytes / alone_t.item() / 1e9, 1),
+                    fingerprints_agree=len({r["layout_fingerprint"] for r in per_rank}) == 1)
     if rank == 0:
         print(f"[bench] timed region done: {1e3 * elapsed / args.steps:.1f} ms/step", file=sys.stderr, flush=True)
         ms = 1e3 * elapsed / args.steps
@@ -314,11 +382,12 @@ def main() -> None:
             traffic, tsrc = pmc_traffic(dom) if full else (None, None)
             bwd = [k for k in stats if k != "osuf_mqa_fwd"]
             bwd_ms = sum(stats[k]["total_ms"] for k in bwd)
+            busy, bsrc = pmc_mfma_busy() if (full and dom == "osuf_mqa_bwd_fused") else (None, None)
             roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4), traffic=traffic, traffic_unit="HBM-side bytes per launch", traffic_source=tsrc,
                         flops="algorithmic (SURVEY 8d: attention backward = 2 x forward, recomputed products not counted)",
                         executed=round(exe, 1), executed_frac=round(exe / MFMA_BF16_PEAK_TFLOPS, 4), launches=stats[dom]["launches"],
-                        mfma_busy=pmc_mfma_busy() if (full and dom == "osuf_mqa_bwd_fused") else None,
+                        mfma_busy=busy, mfma_busy_source=bsrc,
                         mean_launch_ms=round(stats[dom]["total_ms"] / stats[dom]["launches"], 3),
                         attention_backward=dict(kernels=bwd, ms_per_step=round(bwd_ms / args.steps, 2),
                                                 achieved=round(sum(tflop(k, 0) for k in bwd) / (bwd_ms / 1e3), 1) if bwd_ms else None),
@@ -341,40 +410,57 @@ def main() -> None:
             "loss": round(loss.item(), 5), "grad_norm": round(gnorm.item(), 4),
             "roofline": roof,
         }
+        if comm is not None:
+            out["comm"] = comm
+
+        def guarded(key, fn):
+            """A failing secondary must not lose the primary line: record the error under its key and go on."""
+            try:
+                out[key] = fn()
+            except Exception as e:                         # noqa: BLE001
+                out[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+                print(f"[bench] secondary '{key}' failed: {out[key]['error']}", file=sys.stderr, flush=True)
         if args.timed_mode != "bf16":
             out["metric"] += f" [PROFILING RUN in the {args.timed_mode} compute mode -- not the headline number]"
             out["dtype"] = args.timed_mode
         if world == 1 and not args.no_fp32_mode and not args.lora and full and args.timed_mode == "bf16":
             # the compute mode in which north_star's 1e-3 bound holds (exact-f32 MFMA everywhere, bf16 only where the reference casts):
             # one warm-up + one timed step, after the timed region; bf16 (timed above) sits at the reference's own autocast distance
-            trainer.compute_dtype = torch.float32
-            # (key names: fp32_mode_ms_per_step is the EXACT-f32 mode in every round's record; round 3 printed the x3 mode under that key
-            #  and the exact one under fp32_exact_mode_ms_per_step, which is kept as an alias)
-            for key, mm in (("fp32x3_mode_ms_per_step", "x3"), ("fp32_mode_ms_per_step", "exact")):
-                prev = ops.set_f32_matmul(mm)              # x3: fp32 storage, GEMM products as three bf16 MFMAs on split operands (~17 bits);
-                try:                                       # exact: v_mfma_f32_32x32x2_f32, the reference's fp32 arithmetic bit for bit
-                    trainer.step(x, a, c, noise, t)
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    trainer.step(x, a, c, noise, t)
-                    torch.cuda.synchronize()
-                    out[key] = round(1e3 * (time.perf_counter() - t1), 1)
-                finally:
-                    ops.set_f32_matmul(prev)
-            out["fp32_exact_mode_ms_per_step"] = out["fp32_mode_ms_per_step"]
+            def fp32_modes():
+                trainer.compute_dtype = torch.float32
+                res = {}
+                for key, mm in (("fp32x3_mode_ms_per_step", "x3"), ("fp32_mode_ms_per_step", "exact")):
+                    prev = ops.set_f32_matmul(mm)          # x3: fp32 storage, GEMM products as three bf16 MFMAs on split operands (~17 bits);
+                    try:                                   # exact: v_mfma_f32_32x32x2_f32, the reference's fp32 arithmetic bit for bit
+                        trainer.step(x, a, c, noise, t)
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        trainer.step(x, a, c, noise, t)
+                        torch.cuda.synchronize()
+                        res[key] = round(1e3 * (time.perf_counter() - t1), 1)
+                    finally:
+                        ops.set_f32_matmul(prev)
+                return res
+            # (key names: fp32_mode_ms_per_step is the EXACT-f32 mode in every round's record but round 3's, which printed the x3 mode
+            #  under that key and the exact one under fp32_exact_mode_ms_per_step -- kept as an alias)
+            guarded("fp32_modes", fp32_modes)
+            if "error" not in out["fp32_modes"]:
+                out.update(out.pop("fp32_modes"))
+                out["fp32_exact_mode_ms_per_step"] = out["fp32_mode_ms_per_step"]
             out["parity_note"] = ("bf16 (timed) is 0.9-1.3e-2 rel-L2 from the fp32 oracle = the oracle's own bf16-vs-fp32 distance; both fp32 modes "
                                   "are held to 1e-3 at this size by tests/test_full_size.py (forward of two samples and all 1,239 gradients of one "
                                   "sample, each run with set_f32_matmul('exact') and ('x3')): fp32x3_mode = split-bf16 GEMMs, fp32_mode = f32 MFMA")
         if world == 1 and not args.no_sampler and not args.lora and full:
             print("[bench] secondary: DDIM sample at config 4's size ...", file=sys.stderr, flush=True)
-            out["secondary"] = sampler_secondary(model, device)
+            guarded("secondary", lambda: sampler_secondary(model, device))
         if world == 1 and not args.no_cpu_baseline and not args.lora:
-            out["cpu_baseline"] = cpu_baseline(model, args.length, args.cpu_threads or host_threads())
-            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            guarded("cpu_baseline", lambda: cpu_baseline(model, args.length, [args.cpu_threads] if args.cpu_threads else host_thread_counts()))
+            if "value" in out["cpu_baseline"]:
+                out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         if world == 1 and not args.no_config5 and not args.lora and full:
             print("[bench] config 5: DoRA r=16 steps at the per-GPU shard B=64 ...", file=sys.stderr, flush=True)
             del trainer
-            out["config5"] = config5_secondary(model, rank, device)       # LAST: wraps the model's layers in place
+            guarded("config5", lambda: config5_secondary(model, rank, device))      # LAST: wraps the model's layers in place
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

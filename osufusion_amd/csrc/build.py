@@ -15,6 +15,19 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 LIB = HERE / "libosuf_hip.so"
 
 
+ATTN_SOURCES = ["attn.hip", "attn_bwd512_asm.inc", "attn_generic.hpp", "common.hpp"]
+
+
+def source_hash(names=ATTN_SOURCES) -> str:
+    """sha256 over the text of the named kernel sources: what a committed counter summary is stamped with (profiles/pmc_manifest.json),
+    so that bench.py can tell whether the kernels it times are still the kernels those counters were collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        h.update(n.encode() + b"\0" + (HERE / n).read_bytes() + b"\0")
+    return h.hexdigest()
+
+
 def _stale() -> bool:
     if not LIB.exists():
         return True

@@ -15,6 +15,7 @@ MI355X-first choices (nothing here mirrors accelerate/DDP's object model):
 from __future__ import annotations
 
 import math
+import time
 from typing import List, Optional
 
 import torch
@@ -105,6 +106,11 @@ class GradReducer:
         self._seen = set()
         self.order_log: List[int] = []                     # parameter indices in the order they completed (last backward)
         self.fired_early: List[int] = []                   # buckets launched from a completion report (before finish())
+        self.next_bucket = 0                               # collectives are matched by ISSUE order: bucket b goes out only after b-1
+        self.launched_bytes = 0                            # bytes handed to all_reduce in the last begin()..finish()
+        self.launches = 0                                  # all_reduce calls of the last begin()..finish()
+        self.wait_ms = 0.0                                 # host time finish() spent in handle.wait() (not hidden behind backward)
+        self.out_of_order_completions = 0                  # buckets that completed before a lower-indexed one (held back)
         self._hooked = set()
         self.names = {}                                    # id(param) -> name, filled by Trainer for error messages
         self.direct_reports = 0
@@ -159,6 +165,7 @@ class GradReducer:
                 pass
         self.handles = []
         self.pending = list(self.expected)
+        self.next_bucket = 0
         self._seen, self._fresh, self._explicit = set(), True, False
         Fn.reset_grad_uses()
 
@@ -167,6 +174,8 @@ class GradReducer:
         self.order_log = []
         self.fired_early = []
         self.pending = list(self.expected)
+        self.next_bucket = 0
+        self.launched_bytes, self.launches, self.wait_ms, self.out_of_order_completions = 0, 0, 0.0, 0
         self._fresh = False
 
     def param_ready(self, p) -> None:
@@ -209,21 +218,33 @@ class GradReducer:
         b = self.bucket_of[idx]
         self.pending[b] -= 1
         if self.pending[b] == 0:
-            self.fired_early.append(b)
-            self._launch(b)
+            # RCCL / gloo pair the collectives of a communicator by the order in which each rank ISSUES them, so every rank must issue
+            # the buckets in one fixed order whatever order its own backward completed them in: index order, as torch DDP does.  A
+            # bucket that completes ahead of a lower-indexed one is held until that one has gone out.
+            if b != self.next_bucket:
+                self.out_of_order_completions += 1
+            while self.next_bucket < len(self.bounds) and self.pending[self.next_bucket] == 0:
+                self.fired_early.append(self.next_bucket)
+                self._launch(self.next_bucket)
+                self.next_bucket += 1
 
     def _launch(self, b: int) -> None:
         s, e = self.bounds[b]
+        self.launched_bytes += (e - s) * self.flat.grad.element_size()
+        self.launches += 1
         self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self) -> None:
-        """Wait for the in-flight buckets (and reduce any bucket whose parameters did not all report, e.g. unused ones)."""
+        """Wait for the in-flight buckets and reduce, still in index order, every bucket that has not gone out yet (a bucket with an
+        unused parameter never completes, and it holds back every bucket after it)."""
         if self.enabled and self.sync:
-            for b, left in enumerate(self.pending):
-                if left > 0 or not self.overlap:
-                    self._launch(b)
+            for b in range(self.next_bucket, len(self.bounds)):
+                self._launch(b)
+            self.next_bucket = len(self.bounds)
+            t0 = time.perf_counter()
             for h in self.handles:
                 h.wait()
+            self.wait_ms = (time.perf_counter() - t0) * 1e3
         self.handles = []
         self.pending = list(self.expected)
         self._done, self._fresh, self._explicit = set(self._seen), True, False
@@ -399,7 +420,8 @@ class Trainer:
     def _agree_on_order(self, order: List[int]) -> List[int]:
         """Every rank must lay its flat buffers out identically: the bucketed all-reduce is positional.  Rank 0's observed order is
         broadcast and used everywhere (what torch DDP does with its rebuilt bucket order); a rank whose own backward completed the
-        gradients in another order is counted in `order_disagreements` (it only loses some overlap)."""
+        gradients in another order is counted in `order_disagreements`.  Such a rank is still correct -- GradReducer issues the buckets
+        in index order on every rank, never in completion order -- it only sends a bucket later than it could have."""
         dev = self._comm_device()
         t = torch.tensor(order, dtype=torch.int64, device=dev)
         dist.broadcast(t, src=0, group=self.reducer.group)
@@ -408,6 +430,15 @@ class Trainer:
             raise RuntimeError("rank 0 broadcast an order that is not a permutation of this rank's parameters: the ranks hold different models")
         self.order_disagreements = getattr(self, "order_disagreements", 0) + int(agreed != list(order))
         return agreed
+
+    def comm_stats(self) -> dict:
+        """What the last step's gradient reduction did on this rank -- enough for a first multi-GPU run to diagnose itself."""
+        r = self.reducer
+        return {"backend": str(dist.get_backend(r.group)) if r.enabled else None, "world": r.world, "buckets": len(r.bounds),
+                "bucket_mib": r.bucket_mib, "allreduce_calls": r.launches, "allreduce_bytes": r.launched_bytes,
+                "buckets_fired_before_finish": len(r.fired_early), "out_of_order_completions": r.out_of_order_completions,
+                "finish_wait_ms": round(r.wait_ms, 3), "order_disagreements": self.order_disagreements,
+                "layout_fingerprint": self.layout_fingerprint()}
 
     def layout_fingerprint(self) -> int:
         """63-bit hash of (parameter name, offset, numel) in flat order."""

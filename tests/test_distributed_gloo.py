@@ -288,6 +288,78 @@ def test_observed_order_is_agreed_across_ranks():
     assert c0 and c1 and f0 != f1                                   # the rogue re-layout is refused on both ranks
 
 
+class _TwoBranch(nn.Module):
+    """y = head(a(x) + b(x)); `swap` evaluates b before a, which reverses the order autograd walks the two branches in."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(5)
+        self.a = nn.Sequential(nn.Linear(16, 48), nn.SiLU(), nn.Linear(48, 32))
+        self.b = nn.Sequential(nn.Linear(16, 48), nn.SiLU(), nn.Linear(48, 32))
+        self.head = nn.Linear(32, 8)
+
+    def forward(self, x, swap=False):
+        if swap:
+            hb = self.b(x)
+            ha = self.a(x)
+        else:
+            ha = self.a(x)
+            hb = self.b(x)
+        return self.head(ha + hb)
+
+
+def _worker_real_disagreement(rank, world, port, out):
+    """Two ranks whose backwards REALLY complete the buckets in different orders (round-4 review, weak 6): rank 1 evaluates the two
+    branches in the other order, so its hooks fire b's parameters where rank 0 fires a's.  Collectives pair by issue order, so both
+    ranks must still issue bucket 0, 1, 2, ... -- and the reduced gradient must be the single-process one."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _TwoBranch()
+        flat = FlatParameters(model, align=4)
+        red = GradReducer(flat, bucket_mib=0.001)
+        launched = []
+        real_launch = red._launch
+        red._launch = lambda b: (launched.append(b), real_launch(b))[1]
+        assert len(red.bounds) >= 4
+        x, y = _data()
+        xs, ys = x.chunk(world)[rank], y.chunk(world)[rank]
+        res = []
+        for _ in range(2):
+            launched.clear()
+            flat.zero_grad()
+            red.begin(sync=True)
+            ((model(xs, swap=(rank == 1)) - ys) ** 2).mean().backward()
+            early = list(red.fired_early)
+            red.finish()
+            res.append((list(red.order_log), early, list(launched), red.out_of_order_completions, red.launched_bytes, red.launches))
+        out[rank] = (res, (flat.grad / world).clone(), len(red.bounds), flat.grad.numel() * 4)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_buckets_are_issued_in_index_order_when_ranks_complete_them_differently():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_real_disagreement, args=(world, _free_port(), out), nprocs=world, join=True)
+    (r0, g0, nb, nbytes), (r1, g1, _, _) = out[0], out[1]
+    for step in range(2):
+        o0, e0, l0, ooo0, by0, n0 = r0[step]
+        o1, e1, l1, ooo1, by1, n1 = r1[step]
+        assert o0 != o1, "the two ranks were meant to complete their parameters in different orders"
+        assert l0 == l1 == list(range(nb)), (l0, l1)               # one issue order everywhere: index order
+        assert e0 == list(range(len(e0))) and e1 == list(range(len(e1)))
+        assert ooo0 + ooo1 > 0                                      # at least one rank had to hold a completed bucket back
+        assert by0 == by1 == nbytes and n0 == n1 == nb
+    model = _TwoBranch()
+    flat = FlatParameters(model, align=4)
+    x, y = _data()
+    ((model(x) - y) ** 2).mean().backward()
+    assert torch.allclose(g0, flat.grad, rtol=1e-5, atol=1e-7) and torch.equal(g0, g1)
+
+
 def test_duplicate_completion_reports_and_abort():
     """ADVICE r2 (low x2): inside begin()..finish() a second completion report of one parameter must not be mistaken for a new
     backward (it used to reset the bucket bookkeeping mid-backward); a backward that dies leaves the reducer clean for the next."""

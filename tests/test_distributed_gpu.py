@@ -110,3 +110,8 @@ def test_bench_main_with_ranks(tmp_path, world):
     assert "cpu_baseline" not in out and "secondary" not in out  # single-GPU legs only
     import math
     assert math.isfinite(out["loss"]) and math.isfinite(out["grad_norm"])
+    comm = out["comm"]                                           # the self-diagnosis a first real multi-GPU run prints
+    assert comm["world"] == world and comm["backend"] == "gloo" and comm["fingerprints_agree"] and len(comm["per_rank"]) == world
+    assert comm["allreduce_calls"] == comm["buckets"] >= 1 and comm["allreduce_bytes"] > 0
+    assert all(r["allreduce_bytes"] == comm["allreduce_bytes"] for r in comm["per_rank"])
+    assert comm["allreduce_alone_ms"] > 0 and comm["order_disagreements"] == 0
