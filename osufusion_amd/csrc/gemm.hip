@@ -797,6 +797,256 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The same 256 x 256 bf16 tile on an 8-phase schedule (cdna_hip_programming.md section 5, "The 256^2 8-phase template"): the loop above
+// drains its LDS-DMA at one __syncthreads() per 64-deep K-step, so DMA latency, fragment reads and MFMAs of a step run one after the other
+// (triage: DMA 1.48 us + MFMA/LDS 1.09 us -> 2.4 us per step).  Here
+//   * a K-tile (64 deep) is four HALF-TILES of 16 KiB -- B0 / A0 / B1 / A1 = the 32 B columns / 64 A rows every wave needs for its first /
+//     second pair of 32-row (32-column) MFMA tiles -- and four PHASES, one 64 x 32 quadrant of every wave's 128 x 64 output per phase:
+//       P1 reads B0, A0 (12 ds_read_b128) -> acc[0..1][0]   P2 reads B1 (4) -> acc[0..1][1]   P3 reads A1 (8) -> acc[2..3][1]   P4 -> acc[2..3][0]
+//     (per accumulator the k order is the loop's above: results are bit-identical);
+//   * every phase stages ONE half-tile (2 global_load_lds_dwordx4 per lane), six half-tiles ahead of the one it reads first: P1 stages
+//     A1(t+1), P2 B0(t+2), P3 A0(t+2), P4 B1(t+2).  The only vector-memory wait of a K-tile is a counted `s_waitcnt vmcnt(6)` in P4 (three
+//     half-tiles stay in flight; K-tile t+1 has landed), never vmcnt(0); the barriers are raw s_barrier (a __syncthreads() would drain);
+//   * a staged half-tile is read one phase after the wait that retires it, and a slot is re-staged two phases after its last read -- one
+//     phase for B0, whose reads an `s_waitcnt lgkmcnt(8)` retires before P1's first barrier;
+//   * waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its 8-MFMA cluster (s_setprio 1) while its partner
+//     reads fragments and issues DMA;
+//   * the fragment reads are inline asm: for a C++ LDS load hipcc waits vmcnt(0) whenever an LDS-DMA is in flight.
+// LDS map: A buf 0 | A buf 1 | B buf 0 | B buf 1, 32 KiB each (fragment reads reach both buffers and every tile row through the 16-bit
+// immediate), then the GroupNorm slots; row / swizzle image of a buffer and the epilogue as in gemm_nt_big_kernel.
+// ---------------------------------------------------------------------------------------------------------
+template <int OFF> __device__ __forceinline__ void lds_read_b128(u32x4& d, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int V> struct IntC { static constexpr int value = V; };
+
+// DBG (timing-only triage builds, OSUF_GEMM_DBG with OSUF_GEMM_8P; results are garbage unless 0): 1 = no MFMA, 2 = no fragment reads,
+// 3 = no DMA, 4 = DMA only
+__device__ uint4 g_zero_row[1024];                           // 16 KiB of zeros: the source "row" of padded / out-of-range A rows (K <= 8192 bf16)
+static constexpr int kP8Tbl = 2 * kBigStage + 2112;          // LDS: per-tap source rows of the tile's 256 A rows, [taps][256] ints, behind the stat slots
+static constexpr int kP8MaxTaps = 16;
+
+template <int DBG = 0>
+__global__ __launch_bounds__(512, 2) void gemm_nt_big8_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  constexpr int BK = 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (g.N + kBig - 1) / kBig;
+  const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;       // tile order as in gemm_nt_big_kernel
+  const int mt = (qid / tiles_n) * 8 + xcd;
+  const int m0 = mt * kBig, n0 = (qid % tiles_n) * kBig;
+  if (m0 >= g.M) return;
+  const char* A = reinterpret_cast<const char*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+  const char* zero = reinterpret_cast<const char*>(g_zero_row);
+  const int ksteps = (g.K + BK - 1) / BK;
+  const int n = g.taps * ksteps;                             // K-tiles (K % 64 == 0: launcher)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
+
+  // The row maps (taps, reflect / nearest-x2 / dgrad geometries) are evaluated ONCE, into an LDS table of source rows (-1: zeros), before the
+  // first DMA is in flight (plain LDS stores + __syncthreads()); a tap switch inside the pipeline is then four ds_read_b32 per lane.
+  {
+    int* tbl = reinterpret_cast<int*>(smem + kP8Tbl);
+    if (tid < kBig) {
+      const int m = m0 + tid;
+      const int b = m / g.rm.Lout, pos = m - b * g.rm.Lout;
+      for (int t = 0; t < g.taps; ++t) {
+        const int src = m < g.M ? map_row(g.rm, pos, t) : -1;
+        tbl[t * kBig + tid] = src >= 0 ? b * g.rm.Lin + src : -1;
+      }
+    }
+    __syncthreads();
+  }
+
+  // DMA roles.  Half-tile s of A = tile rows wr' * 128 + s * 64 + 0..63 (wr' = 0, 1); of B = tile rows wc' * 64 + s * 32 + 0..31
+  // (wc' = 0..3).  A wave moves two 8-row pieces (j) of every half-tile: A rows (wave >> 2) * 128 + s * 64 + (wave & 3) * 16 + 8 j + lane / 8,
+  // B rows (wave >> 1) * 64 + s * 32 + (wave & 1) * 16 + 8 j + lane / 8.  Every K-step is `pointer += 128 B` (zero rows walk the zero row);
+  // W rows beyond N are clamped to N - 1 (their output columns are never stored), so a tap switch on the B side is one uniform delta.
+  const char* pa[2][2];
+  const char* pb[2][2];
+  auto a_row = [&](int s, int j) { return (wave >> 2) * 128 + s * 64 + (wave & 3) * 16 + j * 8 + (lane >> 3); };
+  auto b_row = [&](int s, int j) { return (wave >> 1) * 64 + s * 32 + (wave & 1) * 16 + j * 8 + (lane >> 3); };
+  const long lda_b = g.lda * (long)sizeof(T);
+  auto set_tap_a = [&](int t) {
+    int src[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        asm volatile("ds_read_b32 %0, %1" : "=v"(src[s][j]) : "v"(lds0 + (uint32_t)(kP8Tbl + (t * kBig + a_row(s, j)) * 4)));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(src[0][0]), "+v"(src[0][1]), "+v"(src[1][0]), "+v"(src[1][1]));
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int chunk = ((lane & 7) ^ ((a_row(s, j) >> 1) & 7)) * 16;
+        pa[s][j] = (src[s][j] >= 0 ? A + (long)src[s][j] * lda_b : zero) + chunk;
+      }
+  };
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rb = b_row(s, j);
+      pb[s][j] = reinterpret_cast<const char*>(W + (long)min(n0 + rb, g.N - 1) * g.ldw + ((lane & 7) ^ ((rb >> 1) & 7)) * 8);
+    }
+  const long tap_delta_b = (g.tapstride - (long)ksteps * BK) * (long)sizeof(T);      // from the end of tap t's K range to the start of tap t + 1's
+  const int aw = ((wave >> 2) * 128 + (wave & 3) * 16) * 128;  // LDS byte offsets of this wave's first piece in a half-tile 0
+  const int bw = 65536 + ((wave >> 1) * 64 + (wave & 1) * 16) * 128;
+  int st_kb = 0, st_tap = 0;                                 // (tap, K-step) of the K-tile whose half-tiles are being staged
+  // half-tile H (0 = B0, 1 = A0, 2 = B1, 3 = A1) of the K-tile being staged, into buffer BUF
+  auto stage = [&](auto hc, auto bufc) {
+    constexpr int H = decltype(hc)::value, BUF = decltype(bufc)::value, S = H >> 1;
+    constexpr bool IS_A = (H & 1) != 0;
+    if (DBG != 3) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const char* q = IS_A ? pa[S][j] : pb[S][j];
+        char* dst = smem + BUF * 32768 + (IS_A ? aw + S * 8192 : bw + S * 4096) + j * 1024;
+        __builtin_amdgcn_global_load_lds((gas_ptr)q, (las_ptr)dst, 16, 0, 0);
+        if (IS_A) pa[S][j] += 128; else pb[S][j] += 128;
+      }
+    }
+  };
+  // behind the last half-tile (A1) of a K-tile: on to the next K-tile, and at the end of a tap's K range to the next tap
+  auto next_ktile = [&]() {
+    if (++st_kb == ksteps) {
+      st_kb = 0;
+      if (++st_tap < g.taps) {
+        set_tap_a(st_tap);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) pb[s][j] += tap_delta_b;
+      }
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses: row lr of the wave's first A / B MFMA tile, chunk (2 ks + lh) ^ swizzle; tile i / j, buffer: immediates
+  const int lr = lane & 31, lh = lane >> 5;
+  uint32_t ka[4], kb[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const uint32_t ch = (uint32_t)(((2 * ks + lh) ^ ((lr >> 1) & 7)) << 4);
+    ka[ks] = lds0 + (uint32_t)((wr * 128 + lr) * 128) + ch;
+    kb[ks] = lds0 + 65536u + (uint32_t)((wc * 64 + lr) * 128) + ch;
+  }
+  u32x4 fa[2][4], fb0[4], fb1[4];
+  if (DBG == 2) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      fa[0][ks] = u32x4{(uint32_t)lane, 1u, 2u, 3u}; fa[1][ks] = fa[0][ks]; fb0[ks] = u32x4{(uint32_t)lane, 5u, 6u, 7u}; fb1[ks] = fb0[ks];
+    }
+  }
+#define P8_WAIT_A(cnt)                                                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), \
+               "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]));
+#define P8_WAIT_B(cnt, fb) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));
+#define P8_MFMA(i0, j, fbv)                                                                                                   \
+  if (DBG != 1 && DBG != 4) {                                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                            \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                        \
+      acc[i0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[0][ks]), __builtin_bit_cast(bf16x8, fbv[ks]), acc[i0][j], 0, 0, 0); \
+      acc[i0 + 1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[1][ks]), __builtin_bit_cast(bf16x8, fbv[ks]), acc[i0 + 1][j], 0, 0, 0); \
+    }                                                                                                                         \
+    __builtin_amdgcn_s_setprio(0);                                                                                            \
+  } else {                                                                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) { asm volatile("" ::"v"(fa[0][ks]), "v"(fa[1][ks]), "v"(fbv[ks])); }         \
+  }
+  constexpr bool RD = DBG != 2 && DBG != 4;
+  // one K-tile (four phases) out of buffer BUF; t = its index
+  auto tile = [&](auto bufc, int t) {
+    constexpr int BUF = decltype(bufc)::value, O = BUF * 32768;
+    // ---- P1: B0, A0 -> acc[0..1][0]; stage A1(t + 1)
+    if (RD) {
+      lds_read_b128<O>(fb0[0], kb[0]); lds_read_b128<O>(fb0[1], kb[1]); lds_read_b128<O>(fb0[2], kb[2]); lds_read_b128<O>(fb0[3], kb[3]);
+      __builtin_amdgcn_sched_barrier(0);
+      lds_read_b128<O>(fa[0][0], ka[0]); lds_read_b128<O>(fa[0][1], ka[1]); lds_read_b128<O>(fa[0][2], ka[2]); lds_read_b128<O>(fa[0][3], ka[3]);
+      lds_read_b128<O + 4096>(fa[1][0], ka[0]); lds_read_b128<O + 4096>(fa[1][1], ka[1]); lds_read_b128<O + 4096>(fa[1][2], ka[2]);
+      lds_read_b128<O + 4096>(fa[1][3], ka[3]);
+    }
+    if (t + 1 < n) { stage(IntC<3>{}, IntC<BUF ^ 1>{}); next_ktile(); }
+    if (RD) { P8_WAIT_B(8, fb0) }                               // B0's reads are done before anyone passes the barrier: P2 re-stages B0's slot
+    __builtin_amdgcn_s_barrier();
+    if (RD) { P8_WAIT_A(0) }
+    __builtin_amdgcn_sched_barrier(0);
+    P8_MFMA(0, 0, fb0)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- P2: B1 -> acc[0..1][1]; stage B0(t + 2)
+    if (RD) { lds_read_b128<O + 4096>(fb1[0], kb[0]); lds_read_b128<O + 4096>(fb1[1], kb[1]); lds_read_b128<O + 4096>(fb1[2], kb[2]); lds_read_b128<O + 4096>(fb1[3], kb[3]); }
+    if (t + 2 < n) stage(IntC<0>{}, IntC<BUF>{});
+    __builtin_amdgcn_s_barrier();
+    if (RD) { P8_WAIT_B(0, fb1) }
+    __builtin_amdgcn_sched_barrier(0);
+    P8_MFMA(0, 1, fb1)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- P3: A1 -> acc[2..3][1]; stage A0(t + 2)
+    if (RD) {
+      lds_read_b128<O + 8192>(fa[0][0], ka[0]); lds_read_b128<O + 8192>(fa[0][1], ka[1]); lds_read_b128<O + 8192>(fa[0][2], ka[2]);
+      lds_read_b128<O + 8192>(fa[0][3], ka[3]);
+      lds_read_b128<O + 12288>(fa[1][0], ka[0]); lds_read_b128<O + 12288>(fa[1][1], ka[1]); lds_read_b128<O + 12288>(fa[1][2], ka[2]);
+      lds_read_b128<O + 12288>(fa[1][3], ka[3]);
+    }
+    if (t + 2 < n) stage(IntC<1>{}, IntC<BUF>{});
+    __builtin_amdgcn_s_barrier();
+    if (RD) { P8_WAIT_A(0) }
+    __builtin_amdgcn_sched_barrier(0);
+    P8_MFMA(2, 1, fb1)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- P4: (B0 still in registers) -> acc[2..3][0]; stage B1(t + 2); K-tile t + 1 has landed behind the counted wait
+    if (t + 2 < n) {
+      stage(IntC<2>{}, IntC<BUF>{});
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    P8_MFMA(2, 0, fb0)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // prologue: K-tile 0 and three half-tiles of K-tile 1
+  set_tap_a(0);
+  stage(IntC<0>{}, IntC<0>{}); stage(IntC<1>{}, IntC<0>{}); stage(IntC<2>{}, IntC<0>{}); stage(IntC<3>{}, IntC<0>{});
+  next_ktile();
+  if (n > 1) {
+    stage(IntC<0>{}, IntC<1>{}); stage(IntC<1>{}, IntC<1>{}); stage(IntC<2>{}, IntC<1>{});
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();                   // waves 4-7 run one barrier behind
+  int t = 0;
+  for (; t + 1 < n; t += 2) {
+    tile(IntC<0>{}, t);
+    tile(IntC<1>{}, t + 1);
+  }
+  if (t < n) tile(IntC<0>{}, t);
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef P8_WAIT_A
+#undef P8_WAIT_B
+#undef P8_MFMA
+  gemm_big_epilogue<T>(g, acc, smem, m0, n0, tid, lane, wave, wr, wc);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // k = 3 "same" convolutions (residual.py:70 and their input gradients; mode 0, stride 1, pad 1, L % 256 == 0, K % 64 == 0) on the same
 // 256 x 256 tile with the activation panel SHARED by the three taps.  The plain kernel streams an A tile per (tap, K-step) although
 // tap t's rows are the same rows shifted by t - 1; its loop is bound by the L2 -> LDS feed (touching the next A lines
@@ -2309,6 +2559,7 @@ static int gemm_nt_launch(int dtype, const void* A, long lda, const void* W, lon
                        (!bias || (reinterpret_cast<uintptr_t>(bias) & 31) == 0) && (!rscale || (reinterpret_cast<uintptr_t>(rscale) & 31) == 0);
   if (use_big) {
     const int lds_big = 2 * kBigStage + 2112;          // ring + per-tile GroupNorm stat slots (2 x 258 floats)
+    const int lds_p8 = kP8Tbl + taps * kBig * 4;
     static bool big_attr = false;
     if (!big_attr) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big);
@@ -2331,6 +2582,18 @@ static int gemm_nt_launch(int dtype, const void* A, long lda, const void* W, lon
       (void)halo_attr;
       if (dtype == OSUF_DT_BF16) hipLaunchKernelGGL(gemm_nt_big_halo3_kernel<bf16_t>, grid_big, dim3(512), lds_big, stream, g);
       else hipLaunchKernelGGL(gemm_nt_big_halo3_kernel<float>, grid_big, dim3(512), lds_big, stream, g);
+    } else if (dtype == OSUF_DT_BF16 && getenv("OSUF_GEMM_8P") != nullptr && taps <= kP8MaxTaps && K <= 8192 && K % 64 == 0) {
+      static bool p8_attr = ((void)hipFuncSetAttribute((const void*)gemm_nt_big8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8Tbl + kP8MaxTaps * kBig * 4),
+                             (void)hipFuncSetAttribute((const void*)gemm_nt_big8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8Tbl + kP8MaxTaps * kBig * 4),
+                             (void)hipFuncSetAttribute((const void*)gemm_nt_big8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8Tbl + kP8MaxTaps * kBig * 4),
+                             (void)hipFuncSetAttribute((const void*)gemm_nt_big8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8Tbl + kP8MaxTaps * kBig * 4),
+                             (void)hipFuncSetAttribute((const void*)gemm_nt_big8_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8Tbl + kP8MaxTaps * kBig * 4), true);
+      (void)p8_attr;
+      if (dbg == 1) hipLaunchKernelGGL(gemm_nt_big8_kernel<1>, grid_big, dim3(512), lds_p8, stream, g);
+      else if (dbg == 2) hipLaunchKernelGGL(gemm_nt_big8_kernel<2>, grid_big, dim3(512), lds_p8, stream, g);
+      else if (dbg == 3) hipLaunchKernelGGL(gemm_nt_big8_kernel<3>, grid_big, dim3(512), lds_p8, stream, g);
+      else if (dbg == 4) hipLaunchKernelGGL(gemm_nt_big8_kernel<4>, grid_big, dim3(512), lds_p8, stream, g);
+      else hipLaunchKernelGGL(gemm_nt_big8_kernel<0>, grid_big, dim3(512), lds_p8, stream, g);
     } else if (dtype == OSUF_DT_F32X3) hipLaunchKernelGGL((gemm_nt_big_kernel<float, 0, true>), grid_big, dim3(512), lds_big, stream, g);
     else if (dbg == 1) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 1>), grid_big, dim3(512), lds_big, stream, g);
     else if (dbg == 2) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 2>), grid_big, dim3(512), lds_big, stream, g);

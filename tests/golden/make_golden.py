@@ -236,6 +236,50 @@ def unet_cases() -> None:
     (HERE / "unet_cases.json").write_text(json.dumps(meta, indent=1))
 
 
+def _unet_outputs(net, name, B, L, autocast: bool):
+    """Forward (cond kept) + the training loss and every parameter gradient, in fp32 or under the trainer's autocast context."""
+    import contextlib
+    x, a, c, t, noise = (T(v) for v in synth_inputs(name, B, L))
+    ctx = (lambda: torch.autocast("cpu", dtype=torch.bfloat16)) if autocast else contextlib.nullcontext
+    with torch.no_grad(), ctx():
+        y_cond = net(x, a, t, c, cond_drop_prob=0.0).float()
+    betas = torch.linspace(1e-4, 0.02, 1000, dtype=torch.float32)
+    acp = torch.cumprod(1.0 - betas, 0)
+    xn = acp[t].sqrt()[:, None, None] * x + (1 - acp[t]).sqrt()[:, None, None] * noise
+    net.zero_grad()
+    with ctx():                                            # trainer.py:295: model(...) (loss included) inside accelerator.autocast()
+        pred = net(xn, a, t, c, cond_drop_prob=0.0)
+        loss = torch.nn.functional.mse_loss(pred, noise)
+    loss.backward()
+    grads = {k: p.grad.detach().float().clone() for k, p in net.named_parameters()}
+    return y_cond, pred.detach().float(), loss.detach().float(), grads
+
+
+def unet_autocast_cases() -> None:
+    """The reference's OWN bf16 arithmetic (trainer.py:295,374: `accelerator.autocast()`, mixed precision bf16 by default) on the
+    same patterned weights and inputs as the fp32 fixtures: output, loss, per-parameter gradient norms, and how far each of them sits
+    from the reference's fp32 run -- the floor the timed (bf16) mode of the HIP path is held to (round-4 review, missing 2)."""
+    for name in ("unet_tiny", "unet_mid"):
+        spec = UNET_CASES[name]
+        cfg, B, L = spec["cfg"], spec["B"], spec["L"]
+        net = shim_attend(ref_unet.UNet(**cfg))
+        load_pattern(net)
+        net.train()
+        y32, p32, l32, g32 = _unet_outputs(net, name, B, L, autocast=False)
+        y16, p16, l16, g16 = _unet_outputs(net, name, B, L, autocast=True)
+        rel = lambda u, v: float((u - v).norm() / v.norm().clamp_min(1e-30))       # noqa: E731
+        names = [k for k, _ in net.named_parameters()]
+        f32, f16 = torch.cat([g32[k].flatten() for k in names]), torch.cat([g16[k].flatten() for k in names])
+        save(f"{name}_autocast", y_cond=y16, pred=p16, loss=l16, loss_fp32=l32,
+             grad_norms=np.array([g16[k].norm().item() for k in names], dtype=np.float64),
+             grad_dist=np.array([rel(g16[k], g32[k]) for k in names], dtype=np.float64),   # per parameter: autocast vs fp32, rel-L2
+             out_dist=np.float64(rel(y16, y32)), pred_dist=np.float64(rel(p16, p32)), flat_grad_dist=np.float64(rel(f16, f32)),
+             **{f"g/{k}": g16[k].flatten()[:GRAD_SLICE] for k in names
+                if k.endswith(("final_conv.weight", "down_layers.0.transformers.0.attn.to_q.weight", "middle_transformer.0.ff.0.weight"))})
+        print(f"  {name}: reference autocast vs reference fp32: output {rel(y16, y32):.3e}, pred {rel(p16, p32):.3e}, "
+              f"flat gradient {rel(f16, f32):.3e}, loss {abs(l16.item() - l32.item()) / l32.item():.2e}")
+
+
 def inventory() -> None:
     """State-dict key/shape inventory of the full default model (dim_h=256): 1,239 entries."""
     net = ref_unet.UNet(6, 96, 5, 256)
@@ -247,6 +291,7 @@ def inventory() -> None:
 
 if __name__ == "__main__":
     assert os.path.isdir("/root/reference"), "generator must run next to the reference"
-    module_cases()
-    unet_cases()
-    inventory()
+    only = sys.argv[1:]
+    for fn in (module_cases, unet_cases, unet_autocast_cases, inventory):
+        if not only or fn.__name__ in only:
+            fn()

@@ -565,6 +565,51 @@ def test_unet_bf16_vs_oracle_emulation(golden_dir, case):
     assert e32 < 3 * floor + 1e-2
 
 
+@pytest.mark.parametrize("case", ["unet_tiny", "unet_mid"])
+def test_unet_bf16_vs_reference_autocast(golden_dir, case):
+    """The timed (bf16) mode against the REFERENCE's own bf16 arithmetic: `{case}_autocast.npz` holds the imported reference UNet run under
+    torch.autocast("cpu", bfloat16) (trainer.py:295,374) on the fp32 fixtures' weights and inputs, and its distance from its own fp32
+    run (unet_mid: output 1.08e-2, flat gradient 8.0e-3).  HIP-bf16 is held to the fp32 golden within 1.5 x that distance (output,
+    prediction, flat gradient), and per parameter to 2.5 x / median 1.25 x of the reference-autocast distance on that parameter."""
+    meta, cfgd, model = _build_model(case, golden_dir)
+    net = model.unet
+    g32, g16 = G(golden_dir, case), G(golden_dir, f"{case}_autocast")
+    x, a, c, t, noise = (T(v) for v in synth_inputs(case, meta["B"], meta["L"]))
+    cfg = O.UNetConfig(**cfgd)
+    p = {k: v.requires_grad_() for k, v in O.make_params(cfg, prefix="unet.").items()}
+    xs, as_, cs, ts, ns = (torch.from_numpy(v) for v in synth_inputs(case, meta["B"], meta["L"]))
+    DO.training_loss(p, cfg, xs, as_, cs, ns, ts, cond_drop_prob=0.0).backward()          # oracle fp32 (pinned to the fp32 golden): full gradients
+    with oa.forced_compute_dtype(torch.bfloat16):
+        with torch.no_grad():
+            y = net(x, a, t, c, cond_drop_prob=0.0)
+        loss = model.loss_with(x, a, c, noise, t, cond_drop_prob=0.0)
+        loss.backward()
+    e_out, ref_out = rell2(y, g32["y_cond"]), float(g16["out_dist"])
+    e_vs_autocast = rell2(y, g16["y_cond"])
+    names = meta["param_names"]
+    params = dict(net.named_parameters())
+    got = {k: params[k].grad.detach().float().cpu() for k in names}
+    ref = {k: p["unet." + k].grad for k in names}
+    flat_got, flat_ref = torch.cat([got[k].flatten() for k in names]), torch.cat([ref[k].flatten() for k in names])
+    e_flat, ref_flat = rell2(flat_got, flat_ref), float(g16["flat_grad_dist"])
+    floor = 1e-4 * flat_ref.norm().item() / len(names) ** 0.5
+    d_hip = np.array([(got[k] - ref[k]).norm().item() / max(ref[k].norm().item(), floor) for k in names])
+    d_ref = np.maximum(g16["grad_dist"], 2e-3)
+    ratio = d_hip / d_ref
+    e_loss, ref_loss = abs(loss.item() - float(g32["loss"])) / float(g32["loss"]), abs(float(g16["loss"]) - float(g16["loss_fp32"])) / float(g16["loss_fp32"])
+    iw = int(ratio.argmax())
+    report(f"unet_bf16_vs_reference_autocast/{case}", hip_out_vs_fp32_golden=e_out, reference_autocast_out_vs_fp32=ref_out,
+           hip_out_vs_reference_autocast=e_vs_autocast, hip_flat_grad_vs_fp32=e_flat, reference_autocast_flat_grad_vs_fp32=ref_flat,
+           hip_loss_rel=e_loss, reference_autocast_loss_rel=ref_loss, per_param_ratio_max=ratio.max(), per_param_ratio_median=float(np.median(ratio)),
+           worst_ratio_param=names[iw])
+    assert e_out < 1.5 * ref_out, (e_out, ref_out)
+    assert e_flat < 1.5 * ref_flat, (e_flat, ref_flat)
+    assert e_vs_autocast < 2.0 * ref_out                        # two bf16 roundings of one fp32 function: ~sqrt(2) x apart
+    assert e_loss < max(3 * ref_loss, 1e-3)
+    assert ratio.max() < 2.5, (names[iw], d_hip[iw], d_ref[iw])
+    assert float(np.median(ratio)) < 1.25
+
+
 def test_masked_loss_ragged_batch_and_length_assert(golden_dir):
     """trainer.py:74-95 pads a batch to its longest sample and passes orig_len; diffusion.py:104-110 masks the loss with it and
     diffusion.py:86 raises AssertionError on a length mismatch (which trainer.py:296-299 catches to skip the batch)."""

@@ -173,6 +173,30 @@ def test_unet_forward_backward(golden_dir, case):
             close(got, g[key], 2e-3)
 
 
+@pytest.mark.parametrize("case", ["unet_tiny", "unet_mid"])
+def test_oracle_bf16_emulation_vs_reference_autocast(golden_dir, case):
+    """The oracle's bf16 mode (the rounding points of the HIP bf16 path) against the reference's OWN autocast run
+    (`{case}_autocast.npz`: the imported reference UNet under torch.autocast("cpu", bfloat16), trainer.py:295,374).  Two different
+    placements of bf16 roundings cannot agree to better than either's distance from fp32; what is pinned is that the emulation sits
+    as far from fp32 as the reference's autocast does (0.5x .. 1.5x) and no further from the autocast run than 2x that distance."""
+    meta = json.loads((golden_dir / "unet_cases.json").read_text())[case]
+    cfgd = {k: (tuple(v) if isinstance(v, list) else v) for k, v in meta["cfg"].items()}
+    cfg = O.UNetConfig(**cfgd)
+    p = O.make_params(cfg)
+    x, a, c, t, noise = (T(v) for v in synth_inputs(case, meta["B"], meta["L"]))
+    g32, g16 = G(golden_dir, case), G(golden_dir, f"{case}_autocast")
+    rel = lambda u, v: float((u.double() - T(v).double()).norm() / T(v).double().norm())       # noqa: E731
+    with torch.no_grad():
+        y16 = O.unet_forward(p, cfg, x, a, t, c, cond_drop_prob=0.0, mode="bf16")
+    ref = float(g16["out_dist"])
+    assert abs(rel(T(g16["y_cond"]), g32["y_cond"]) - ref) < 1e-6 * ref + 1e-9      # the fixture's own bookkeeping
+    mine = rel(y16, g32["y_cond"])
+    assert 0.5 * ref < mine < 1.5 * ref, (mine, ref)
+    assert rel(y16, g16["y_cond"]) < 2.0 * ref
+    assert g16["grad_dist"].shape == (len(meta["param_names"]),) and np.isfinite(g16["grad_dist"]).all()
+    assert 5e-3 < float(g16["flat_grad_dist"]) < 2e-2                                # unet_mid 8.0e-3, unet_tiny 1.07e-2
+
+
 def test_state_dict_inventory_full_model(golden_dir):
     inv = json.loads((golden_dir / "state_dict_dim256.json").read_text())
     shapes = dict(O.param_shapes(O.UNetConfig(dim_h=256)))
