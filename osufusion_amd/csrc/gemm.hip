@@ -821,7 +821,7 @@ template <int OFF> __device__ __forceinline__ void lds_read_b128(u32x4& d, uint3
 template <int V> struct IntC { static constexpr int value = V; };
 
 // DBG (timing-only triage builds, OSUF_GEMM_DBG with OSUF_GEMM_8P; results are garbage unless 0): 1 = no MFMA, 2 = no fragment reads,
-// 3 = no DMA, 4 = DMA only
+// 3 = no DMA, 4 = DMA only, 5 = DMA only with B from one hot KiB (A's feed alone), 6 = DMA only with A from one hot KiB (B's feed alone)
 __device__ uint4 g_zero_row[1024];                           // 16 KiB of zeros: the source "row" of padded / out-of-range A rows (K <= 8192 bf16)
 static constexpr int kP8Tbl = 2 * kBigStage + 2112;          // LDS: per-tap source rows of the tile's 256 A rows, [taps][256] ints, behind the stat slots
 static constexpr int kP8MaxTaps = 16;
@@ -905,6 +905,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big8_kernel(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const char* q = IS_A ? pa[S][j] : pb[S][j];
+        if ((DBG == 5 && !IS_A) || (DBG == 6 && IS_A)) q = (IS_A ? A : reinterpret_cast<const char*>(W)) + lane * 16;   // that operand from one hot KiB
         char* dst = smem + BUF * 32768 + (IS_A ? aw + S * 8192 : bw + S * 4096) + j * 1024;
         __builtin_amdgcn_global_load_lds((gas_ptr)q, (las_ptr)dst, 16, 0, 0);
         if (IS_A) pa[S][j] += 128; else pb[S][j] += 128;
@@ -954,7 +955,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big8_kernel(GemmArgs g) {
                "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]));
 #define P8_WAIT_B(cnt, fb) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));
 #define P8_MFMA(i0, j, fbv)                                                                                                   \
-  if (DBG != 1 && DBG != 4) {                                                                                                 \
+  if (DBG != 1 && DBG < 4) {                                                                                                  \
     __builtin_amdgcn_s_setprio(1);                                                                                            \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                        \
       acc[i0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[0][ks]), __builtin_bit_cast(bf16x8, fbv[ks]), acc[i0][j], 0, 0, 0); \
@@ -964,7 +965,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big8_kernel(GemmArgs g) {
   } else {                                                                                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) { asm volatile("" ::"v"(fa[0][ks]), "v"(fa[1][ks]), "v"(fbv[ks])); }         \
   }
-  constexpr bool RD = DBG != 2 && DBG != 4;
+  constexpr bool RD = DBG != 2 && DBG < 4;
   // one K-tile (four phases) out of buffer BUF; t = its index
   auto tile = [&](auto bufc, int t) {
     constexpr int BUF = decltype(bufc)::value, O = BUF * 32768;
@@ -2582,18 +2583,13 @@ static int gemm_nt_launch(int dtype, const void* A, long lda, const void* W, lon
       (void)halo_attr;
       if (dtype == OSUF_DT_BF16) hipLaunchKernelGGL(gemm_nt_big_halo3_kernel<bf16_t>, grid_big, dim3(512), lds_big, stream, g);
       else hipLaunchKernelGGL(gemm_nt_big_halo3_kernel<float>, grid_big, dim3(512), lds_big, stream, g);
-    } else if (dtype == OSUF_DT_BF16 && getenv("OSUF_GEMM_8P") != nullptr && taps <= kP8MaxTaps && K <= 8192 && K % 64 == 0) {
-      static bool p8_attr = ((void)hipFuncSetAttribute((const void*)gemm_nt_big8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8Tbl + kP8MaxTaps * kBig * 4),
-                             (void)hipFuncSetAttribute((const void*)gemm_nt_big8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8Tbl + kP8MaxTaps * kBig * 4),
-                             (void)hipFuncSetAttribute((const void*)gemm_nt_big8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8Tbl + kP8MaxTaps * kBig * 4),
-                             (void)hipFuncSetAttribute((const void*)gemm_nt_big8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8Tbl + kP8MaxTaps * kBig * 4),
-                             (void)hipFuncSetAttribute((const void*)gemm_nt_big8_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8Tbl + kP8MaxTaps * kBig * 4), true);
-      (void)p8_attr;
-      if (dbg == 1) hipLaunchKernelGGL(gemm_nt_big8_kernel<1>, grid_big, dim3(512), lds_p8, stream, g);
-      else if (dbg == 2) hipLaunchKernelGGL(gemm_nt_big8_kernel<2>, grid_big, dim3(512), lds_p8, stream, g);
-      else if (dbg == 3) hipLaunchKernelGGL(gemm_nt_big8_kernel<3>, grid_big, dim3(512), lds_p8, stream, g);
-      else if (dbg == 4) hipLaunchKernelGGL(gemm_nt_big8_kernel<4>, grid_big, dim3(512), lds_p8, stream, g);
-      else hipLaunchKernelGGL(gemm_nt_big8_kernel<0>, grid_big, dim3(512), lds_p8, stream, g);
+    } else if (dtype == OSUF_DT_BF16 && getenv("OSUF_GEMM_NO8P") == nullptr && taps <= kP8MaxTaps && K <= 8192 && K % 64 == 0) {
+      // (the 8-phase loop; OSUF_GEMM_NO8P=1 = the one-barrier-per-K-step loop above, for A/B runs and for K % 64 != 0 / more than 16 taps)
+      const int lds_p8_max = kP8Tbl + kP8MaxTaps * kBig * 4;
+#define P8_CASE(D) case D: { static bool a_ = ((void)hipFuncSetAttribute((const void*)gemm_nt_big8_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_p8_max), true); (void)a_; \
+                             hipLaunchKernelGGL(gemm_nt_big8_kernel<D>, grid_big, dim3(512), lds_p8, stream, g); } break;
+      switch (dbg) { P8_CASE(1) P8_CASE(2) P8_CASE(3) P8_CASE(4) P8_CASE(5) P8_CASE(6) default: P8_CASE(0) }
+#undef P8_CASE
     } else if (dtype == OSUF_DT_F32X3) hipLaunchKernelGGL((gemm_nt_big_kernel<float, 0, true>), grid_big, dim3(512), lds_big, stream, g);
     else if (dbg == 1) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 1>), grid_big, dim3(512), lds_big, stream, g);
     else if (dbg == 2) hipLaunchKernelGGL((gemm_nt_big_kernel<bf16_t, 2>), grid_big, dim3(512), lds_big, stream, g);

@@ -52,7 +52,7 @@ def report(name, **vals):
     import os
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/parity_metrics.jsonl", "a") as f:
-        f.write(json.dumps({"test": name, **{k: float(v) for k, v in vals.items()}}) + "\n")
+        f.write(json.dumps({"test": name, **{k: (v if isinstance(v, (list, str)) else float(v)) for k, v in vals.items()}}) + "\n")
 
 
 def load_pattern(module):

@@ -1,0 +1,82 @@
+"""Round 5 GPU checks: the 8-phase 256 x 256 GEMM loops against the kernels they replace."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from osufusion_amd import functional as Fn
+from osufusion_amd import ops
+from tests.test_hip_parity import B, DEV, relmax, report
+
+
+@pytest.mark.parametrize("kind,k,L,Cin", [("same", 1, 520, 64),      # one K-tile: prologue only, no steady state
+                                          ("same", 1, 200, 128),     # two K-tiles
+                                          ("same", 1, 264, 192),     # odd number of K-tiles
+                                          ("same", 3, 200, 64),      # taps switch on every K-tile (LDS table of source rows), zero rows at sample edges
+                                          ("same", 3, 136, 256),
+                                          ("down", 3, 96, 128),      # stride 2 + right reflect (row-map mode 1); its input gradient: mode 3, four taps
+                                          ("up", 3, 56, 64),         # nearest x2 (mode 2); its input gradient: stride 2
+                                          ("same", 15, 64, 64)])     # 15 taps (the table's upper range is 16)
+def test_gemm_8phase_kernel_bit_exact(monkeypatch, kind, k, L, Cin):
+    """gemm_nt_big8_kernel (8-phase schedule: counted vmcnt, raw barriers, staggered wave halves; the default 256 x 256 forward / input-gradient
+    kernel of residual.py:70,115, unet.py:118-123,149-156 for K % 64 == 0) forced onto small ragged shapes -- M, N tails, every row-map mode,
+    every epilogue option (bias, SiLU, pre-activation copy, residual x per-sample scale, GroupNorm sums; the dgrad's residual) -- against
+    (a) the one-barrier-per-K-step 256 x 256 kernel (OSUF_GEMM_NO8P): same accumulation order, same epilogue code: bit-identical outputs;
+    (b) the 128 x 128 kernel: bit-identical pre-activations (the epilogues differ in mul+add contraction by at most a bf16 ulp)."""
+    Cout = 328
+    x = torch.randn(B, L, Cin, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin, k, device=DEV) / (Cin * k) ** 0.5)
+    bias = torch.randn(Cout, device=DEV)
+    Lout = {"same": L, "down": L // 2, "up": 2 * L}[kind]
+    res = torch.randn(B, Lout, Cout, device=DEV).to(torch.bfloat16)
+    rscale = torch.rand(B, Cout, device=DEV)
+    outs = {}
+    for name, big, no8p in (("small", "0", None), ("plain", "1", "1"), ("p8", "1", None)):
+        monkeypatch.setenv("OSUF_GEMM_BIG_MIN_TILES", big)
+        if no8p:
+            monkeypatch.setenv("OSUF_GEMM_NO8P", no8p)
+        else:
+            monkeypatch.delenv("OSUF_GEMM_NO8P", raising=False)
+        stats = torch.zeros(B, 2, dtype=torch.float64, device=DEV)
+        y, pre = Fn.conv_forward(x, w, bias, Fn.PackCache(), kind, None, act=1, residual=res, rscale=rscale, stats=stats, want_pre=True)
+        dx = Fn.conv_dgrad(y, w, Fn.PackCache(), kind, L, residual=x)
+        outs[name] = (y.float(), pre.float(), stats.clone(), dx.float())
+    monkeypatch.delenv("OSUF_GEMM_BIG_MIN_TILES")
+    monkeypatch.delenv("OSUF_GEMM_NO8P", raising=False)
+    for a, b_ in zip(outs["p8"][:2] + outs["p8"][3:], outs["plain"][:2] + outs["plain"][3:]):
+        assert torch.equal(a, b_)
+    assert torch.allclose(outs["p8"][2], outs["plain"][2], rtol=1e-6)          # LDS float atomics inside a tile: order only
+    assert torch.equal(outs["p8"][1], outs["small"][1])
+    xq, wq = x.float(), w.to(torch.bfloat16).float()
+    if kind == "same":
+        ref = F.conv1d(xq.permute(0, 2, 1), wq, bias, padding=k // 2)
+    elif kind == "down":
+        ref = F.conv1d(F.pad(xq.permute(0, 2, 1), (0, 1), mode="reflect"), wq, bias, stride=2)
+    else:
+        ref = F.conv1d(F.interpolate(xq.permute(0, 2, 1), scale_factor=2.0, mode="nearest"), wq, bias, padding=1)
+    e = relmax(outs["p8"][1].permute(0, 2, 1), ref)
+    report(f"gemm_8phase/{kind}_k{k}_L{L}_C{Cin}", pre_vs_conv1d=e)
+    assert e < 1e-2
+
+
+def test_gemm_8phase_chip_filling_shapes_repeatable():
+    """The same comparison on chip-filling shapes (every CU busy, DMA queues loaded -- where a fragment read overtaking its LDS-DMA would
+    show), ten launches each: bit-identical to the one-barrier loop every time."""
+    import os
+    for M, N, K, taps in ((131072, 256, 256, 1), (65536, 1152, 256, 1), (32768, 512, 1024, 1), (32768, 768, 768, 3), (16384, 1024, 2048, 1)):
+        L = 4096
+        x = torch.randn(M, K, device=DEV).bfloat16()
+        w = (torch.randn(taps, N, K, device=DEV) * 0.05).bfloat16()
+        kw = dict(taps=taps, lin=L, lout=L, stride=1, pad=taps // 2) if taps > 1 else {}
+        os.environ["OSUF_GEMM_NO8P"] = "1"
+        os.environ["OSUF_GEMM_NOHALO"] = "1"
+        try:
+            ref = ops.gemm_nt(x, w, None, **kw)
+            del os.environ["OSUF_GEMM_NO8P"]
+            for _ in range(10):
+                got = ops.gemm_nt(x, w, None, **kw)
+                assert torch.equal(got, ref), (M, N, K, taps)
+        finally:
+            os.environ.pop("OSUF_GEMM_NO8P", None)
+            os.environ.pop("OSUF_GEMM_NOHALO", None)

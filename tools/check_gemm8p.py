@@ -1,4 +1,4 @@
-"""The 8-phase 256^2 NT GEMM (gemm_nt_big8_kernel, OSUF_GEMM_8P=1) against the one-barrier-per-K-step 256^2 kernel it replaces: bit-identical
+"""The 8-phase 256^2 NT GEMM (gemm_nt_big8_kernel, the default; OSUF_GEMM_NO8P=1 selects the old loop) against the one-barrier-per-K-step 256^2 kernel it replaces: bit-identical
 outputs on chip-filling shapes over repeated launches (a race screen: a fragment read that overtakes its DMA shows up as a changed tile), then
 the timing of both, interleaved in ONE process (cdna_hip_programming.md 5.4 rule 24).
     python tools/check_gemm8p.py [--rounds 5] [--iters 20]"""
@@ -14,8 +14,8 @@ SHAPES = [(256, 256, 1), (1152, 256, 1), (1024, 256, 1), (256, 1024, 1), (256, 6
 
 
 def run(x, w, out, p8, taps=1, L=None):
-    if p8: os.environ["OSUF_GEMM_8P"] = "1"
-    else: os.environ.pop("OSUF_GEMM_8P", None)
+    if p8: os.environ.pop("OSUF_GEMM_NO8P", None)
+    else: os.environ["OSUF_GEMM_NO8P"] = "1"
     if taps == 1:
         ops.gemm_nt(x, w, None, out=out)
     else:
