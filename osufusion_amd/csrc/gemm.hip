@@ -1196,6 +1196,211 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_big_halo3_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The shared-panel k = 3 kernel on the 8-phase schedule of gemm_nt_big8_kernel (bf16).  A "K-tile" is one (K-step, tap): four phases over
+// the K-step's activation panel (rows shifted by the tap) and the tap's B tile.  B half-tiles are staged two K-tiles ahead as there (P2
+// stages B0(t+2), P4 B1(t+2)); the NEXT K-step's panel (33 pieces of 8 rows) rides the free staging slots of the three taps (P1 / P3 of taps
+// 0 and 1, P1 of tap 2) into the other panel buffer, whose last reader was the previous K-step's tap 2 / P3.  One counted wait per K-tile
+// (P4): everything up to B1(t+1) -- and, at tap 2, the whole next panel -- has landed, the 4 (6 with panel pieces behind it) youngest
+// LDS-DMA stay in flight.  Accumulation order = gemm_nt_big_halo3_kernel's (K-steps outer, taps inner): bit-identical.
+// LDS: panel 0 | panel 1 (264 rows x 128 B each) | B buf 0 | B buf 1 (32 KiB each) | GroupNorm slots.
+// ---------------------------------------------------------------------------------------------------------
+static constexpr int kH8B = 2 * kPanelBytes;                 // 67,584: B ring behind the two panels
+
+template <int DBG = 0>
+__global__ __launch_bounds__(512, 2) void gemm_nt_big8_halo3_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (g.N + kBig - 1) / kBig;
+  const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;       // tile order as in gemm_nt_big_kernel
+  const int mt = (qid / tiles_n) * 8 + xcd;
+  const int m0 = mt * kBig, n0 = (qid % tiles_n) * kBig;
+  if (m0 >= g.M) return;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* W = reinterpret_cast<const T*>(g.W);
+  const char* zero = reinterpret_cast<const char*>(g_zero_row);
+  const int L = g.rm.Lout;
+  const int pos0 = m0 % L;                                   // position of the tile's first row inside its sample (a tile never straddles samples)
+  const int ksteps = g.K / 64;
+  const int n = 3 * ksteps;                                  // K-tiles
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(LDS_PTR(char))smem;
+
+  // A panel: group gi (8 rows) of wave w is 4 w + i, i < 4; wave 0 also loads group 32 (rows 256 .. 263, of which 256 and 257 are read).
+  // Rows outside the sample walk the zero row.
+  const char* pa[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int r = ((i < 4 ? wave * 4 + i : 32) * 8) + (lane >> 3);       // panel row; activation row m0 - 1 + r
+    const int pos = pos0 - 1 + r;
+    const bool ok = r < 258 && pos >= 0 && pos < L;
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    pa[i] = (ok ? reinterpret_cast<const char*>(A + (long)(m0 - 1 + r) * g.lda) : zero) + c * 16;
+  }
+  // B: half-tile s = tile rows wc' * 64 + s * 32 + 0..31; this wave's two pieces j: rows (wave >> 1) * 64 + s * 32 + (wave & 1) * 16 + 8 j + lane / 8.
+  // Running pointers through (K-step, tap) order; W rows beyond N are clamped (their columns are never stored).
+  const char* pb[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rb = (wave >> 1) * 64 + s * 32 + (wave & 1) * 16 + j * 8 + (lane >> 3);
+      pb[s][j] = reinterpret_cast<const char*>(W + (long)min(n0 + rb, g.N - 1) * g.ldw + ((lane & 7) ^ ((rb >> 1) & 7)) * 8);
+    }
+  const long tapb = g.tapstride * (long)sizeof(T);
+  const long next_k = 128 - 2 * tapb;                        // from tap 2 of a K-step to tap 0 of the next
+  const int bw = kH8B + ((wave >> 1) * 64 + (wave & 1) * 16) * 128;
+  int st_tap = 0;                                            // tap of the B tile being staged
+  auto stage_b = [&](auto sc, auto bufc) {                    // half-tile S of the B tile being staged, into buffer BUF; behind B1: on to the next B tile
+    constexpr int S = decltype(sc)::value, BUF = decltype(bufc)::value;
+    if (DBG != 3) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_global_load_lds((gas_ptr)pb[S][j], (las_ptr)(smem + bw + BUF * 32768 + S * 4096 + j * 1024), 16, 0, 0);
+    }
+    if (S == 1) {
+      const long d = st_tap < 2 ? tapb : next_k;
+      st_tap = st_tap < 2 ? st_tap + 1 : 0;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pb[s][j] += d;
+    }
+  };
+  auto stage_a = [&](auto ic, auto panelc) {                  // piece I of this wave into panel PANEL; advances to the next K-step
+    constexpr int I = decltype(ic)::value, PANEL = decltype(panelc)::value;
+    const int gi = I < 4 ? wave * 4 + I : 32;
+    if (DBG != 3) __builtin_amdgcn_global_load_lds((gas_ptr)pa[I], (las_ptr)(smem + PANEL * kPanelBytes + gi * 1024), 16, 0, 0);
+    pa[I] += 128;
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  uint32_t kb_[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kb_[ks] = lds0 + (uint32_t)kH8B + (uint32_t)((wc * 64 + lr) * 128) + (uint32_t)(((2 * ks + lh) ^ ((lr >> 1) & 7)) << 4);
+  u32x4 fa[2][4], fb0[4], fb1[4];
+#define H8_WAIT_A(cnt)                                                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), \
+               "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]));
+#define H8_WAIT_B(cnt, fb) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));
+#define H8_MFMA(i0, j, fbv)                                                                                                   \
+  if (DBG != 1) {                                                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                                            \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                        \
+      acc[i0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[0][ks]), __builtin_bit_cast(bf16x8, fbv[ks]), acc[i0][j], 0, 0, 0); \
+      acc[i0 + 1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[1][ks]), __builtin_bit_cast(bf16x8, fbv[ks]), acc[i0 + 1][j], 0, 0, 0); \
+    }                                                                                                                         \
+    __builtin_amdgcn_s_setprio(0);                                                                                            \
+  } else {                                                                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) { asm volatile("" ::"v"(fa[0][ks]), "v"(fa[1][ks]), "v"(fbv[ks])); }         \
+  }
+  // one K-tile = (K-step in panel PANEL, tap TAP), B tile in buffer BUF; t = its index, more_k: another K-step follows this one
+  auto tile = [&](auto panelc, auto bufc, auto tapc, int t, bool more_k) {
+    constexpr int PANEL = decltype(panelc)::value, BUF = decltype(bufc)::value, TAP = decltype(tapc)::value;
+    constexpr int OA = PANEL * kPanelBytes, OB = BUF * 32768;
+    // fragment rows of this tap: panel row wr * 128 + i * 32 + lr + TAP (the swizzle follows the shifted row)
+    uint32_t ka[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      ka[ks] = lds0 + (uint32_t)((wr * 128 + lr + TAP) * 128) + (uint32_t)(((2 * ks + lh) ^ (((lr + TAP) >> 1) & 7)) << 4);
+    // ---- P1: B0, A rows 0..63 -> acc[0..1][0]; a piece of the next panel
+    lds_read_b128<OB>(fb0[0], kb_[0]); lds_read_b128<OB>(fb0[1], kb_[1]); lds_read_b128<OB>(fb0[2], kb_[2]); lds_read_b128<OB>(fb0[3], kb_[3]);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_read_b128<OA>(fa[0][0], ka[0]); lds_read_b128<OA>(fa[0][1], ka[1]); lds_read_b128<OA>(fa[0][2], ka[2]); lds_read_b128<OA>(fa[0][3], ka[3]);
+    lds_read_b128<OA + 4096>(fa[1][0], ka[0]); lds_read_b128<OA + 4096>(fa[1][1], ka[1]); lds_read_b128<OA + 4096>(fa[1][2], ka[2]);
+    lds_read_b128<OA + 4096>(fa[1][3], ka[3]);
+    if (more_k) {
+      if (TAP == 0) stage_a(IntC<0>{}, IntC<PANEL ^ 1>{});
+      if (TAP == 1) stage_a(IntC<2>{}, IntC<PANEL ^ 1>{});
+      if (TAP == 2 && wave == 0) stage_a(IntC<4>{}, IntC<PANEL ^ 1>{});
+    }
+    H8_WAIT_B(8, fb0)                                           // B0's reads are done before anyone passes the barrier: P2 re-stages B0's slot
+    __builtin_amdgcn_s_barrier();
+    H8_WAIT_A(0)
+    __builtin_amdgcn_sched_barrier(0);
+    H8_MFMA(0, 0, fb0)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- P2: B1 -> acc[0..1][1]; stage B0(t + 2)
+    lds_read_b128<OB + 4096>(fb1[0], kb_[0]); lds_read_b128<OB + 4096>(fb1[1], kb_[1]); lds_read_b128<OB + 4096>(fb1[2], kb_[2]); lds_read_b128<OB + 4096>(fb1[3], kb_[3]);
+    if (t + 2 < n) stage_b(IntC<0>{}, IntC<BUF>{});
+    __builtin_amdgcn_s_barrier();
+    H8_WAIT_B(0, fb1)
+    __builtin_amdgcn_sched_barrier(0);
+    H8_MFMA(0, 1, fb1)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- P3: A rows 64..127 -> acc[2..3][1]; a piece of the next panel
+    lds_read_b128<OA + 8192>(fa[0][0], ka[0]); lds_read_b128<OA + 8192>(fa[0][1], ka[1]); lds_read_b128<OA + 8192>(fa[0][2], ka[2]);
+    lds_read_b128<OA + 8192>(fa[0][3], ka[3]);
+    lds_read_b128<OA + 12288>(fa[1][0], ka[0]); lds_read_b128<OA + 12288>(fa[1][1], ka[1]); lds_read_b128<OA + 12288>(fa[1][2], ka[2]);
+    lds_read_b128<OA + 12288>(fa[1][3], ka[3]);
+    if (more_k) {
+      if (TAP == 0) stage_a(IntC<1>{}, IntC<PANEL ^ 1>{});
+      if (TAP == 1) stage_a(IntC<3>{}, IntC<PANEL ^ 1>{});
+    }
+    __builtin_amdgcn_s_barrier();
+    H8_WAIT_A(0)
+    __builtin_amdgcn_sched_barrier(0);
+    H8_MFMA(2, 1, fb1)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- P4: (B0 still in registers) -> acc[2..3][0]; stage B1(t + 2); B(t + 1) -- at tap 2 also the next panel -- has landed behind the wait
+    if (t + 2 < n) {
+      stage_b(IntC<1>{}, IntC<BUF>{});
+      // younger than B1(t + 1): this tile's panel pieces (taps 0, 1: two) and B0 / B1(t + 2) (two each); tap 2's piece must land too
+      if (TAP < 2 && more_k) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    H8_MFMA(2, 0, fb0)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // prologue: panel 0, B tiles 0 and 1
+  stage_a(IntC<0>{}, IntC<0>{}); stage_a(IntC<1>{}, IntC<0>{}); stage_a(IntC<2>{}, IntC<0>{}); stage_a(IntC<3>{}, IntC<0>{});
+  if (wave == 0) stage_a(IntC<4>{}, IntC<0>{});
+  stage_b(IntC<0>{}, IntC<0>{}); stage_b(IntC<1>{}, IntC<0>{});
+  stage_b(IntC<0>{}, IntC<1>{}); stage_b(IntC<1>{}, IntC<1>{});
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");             // panel 0 and B tile 0; B tile 1 stays in flight
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();                   // waves 4-7 run one barrier behind
+  int kb = 0;
+  for (; kb + 1 < ksteps; kb += 2) {
+    tile(IntC<0>{}, IntC<0>{}, IntC<0>{}, 3 * kb, true);
+    tile(IntC<0>{}, IntC<1>{}, IntC<1>{}, 3 * kb + 1, true);
+    tile(IntC<0>{}, IntC<0>{}, IntC<2>{}, 3 * kb + 2, true);
+    const bool more = kb + 2 < ksteps;
+    tile(IntC<1>{}, IntC<1>{}, IntC<0>{}, 3 * kb + 3, more);
+    tile(IntC<1>{}, IntC<0>{}, IntC<1>{}, 3 * kb + 4, more);
+    tile(IntC<1>{}, IntC<1>{}, IntC<2>{}, 3 * kb + 5, more);
+  }
+  if (kb < ksteps) {
+    tile(IntC<0>{}, IntC<0>{}, IntC<0>{}, 3 * kb, false);
+    tile(IntC<0>{}, IntC<1>{}, IntC<1>{}, 3 * kb + 1, false);
+    tile(IntC<0>{}, IntC<0>{}, IntC<2>{}, 3 * kb + 2, false);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef H8_WAIT_A
+#undef H8_WAIT_B
+#undef H8_MFMA
+  gemm_big_epilogue<T>(g, acc, smem, m0, n0, tid, lane, wave, wr, wc);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Skinny-N variant (N <= 32: the rank-r LoRA products u = A(x) and du = dy (s g B), functional.adapter_grads): a 256 x 32 tile per
 // workgroup -- 8 waves x one 32x32 MFMA tile -- so the DMA traffic is the A panel only (the 128 / 256-wide tiles spend 4-8x the
 // MFMAs and B-side DMA slots on zero columns).  Same loader (per-tap row maps, incremental pointers), 2 x 36 KiB ring -> two
@@ -2581,7 +2786,12 @@ static int gemm_nt_launch(int dtype, const void* A, long lda, const void* W, lon
       static bool halo_attr = ((void)hipFuncSetAttribute((const void*)gemm_nt_big_halo3_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big),
                                (void)hipFuncSetAttribute((const void*)gemm_nt_big_halo3_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big), true);
       (void)halo_attr;
-      if (dtype == OSUF_DT_BF16) hipLaunchKernelGGL(gemm_nt_big_halo3_kernel<bf16_t>, grid_big, dim3(512), lds_big, stream, g);
+      if (dtype == OSUF_DT_BF16 && getenv("OSUF_GEMM_NO8P") == nullptr && K <= 8192) {
+        const int lds_h8 = kH8B + 65536 + 2112;
+        static bool h8_attr = ((void)hipFuncSetAttribute((const void*)gemm_nt_big8_halo3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_h8), true);
+        (void)h8_attr;
+        hipLaunchKernelGGL(gemm_nt_big8_halo3_kernel<0>, grid_big, dim3(512), lds_h8, stream, g);
+      } else if (dtype == OSUF_DT_BF16) hipLaunchKernelGGL(gemm_nt_big_halo3_kernel<bf16_t>, grid_big, dim3(512), lds_big, stream, g);
       else hipLaunchKernelGGL(gemm_nt_big_halo3_kernel<float>, grid_big, dim3(512), lds_big, stream, g);
     } else if (dtype == OSUF_DT_BF16 && getenv("OSUF_GEMM_NO8P") == nullptr && taps <= kP8MaxTaps && K <= 8192 && K % 64 == 0) {
       // (the 8-phase loop; OSUF_GEMM_NO8P=1 = the one-barrier-per-K-step loop above, for A/B runs and for K % 64 != 0 / more than 16 taps)

@@ -64,13 +64,17 @@ def test_gemm_8phase_chip_filling_shapes_repeatable():
     """The same comparison on chip-filling shapes (every CU busy, DMA queues loaded -- where a fragment read overtaking its LDS-DMA would
     show), ten launches each: bit-identical to the one-barrier loop every time."""
     import os
-    for M, N, K, taps in ((131072, 256, 256, 1), (65536, 1152, 256, 1), (32768, 512, 1024, 1), (32768, 768, 768, 3), (16384, 1024, 2048, 1)):
-        L = 4096
+    for M, N, K, taps, halo in ((131072, 256, 256, 1, False), (65536, 1152, 256, 1, False), (32768, 512, 1024, 1, False), (32768, 768, 768, 3, False),
+                                (16384, 1024, 2048, 1, False),
+                                # the shared-panel k = 3 kernel (gemm_nt_big8_halo3_kernel) against gemm_nt_big_halo3_kernel: odd / even K-step counts, one K-step
+                                (65536, 256, 256, 3, True), (32768, 768, 768, 3, True), (32768, 512, 64, 3, True), (16384, 1024, 1024, 3, True), (32768, 328, 192, 3, True)):
+        L = 4096 if not halo else 512
         x = torch.randn(M, K, device=DEV).bfloat16()
         w = (torch.randn(taps, N, K, device=DEV) * 0.05).bfloat16()
         kw = dict(taps=taps, lin=L, lout=L, stride=1, pad=taps // 2) if taps > 1 else {}
         os.environ["OSUF_GEMM_NO8P"] = "1"
-        os.environ["OSUF_GEMM_NOHALO"] = "1"
+        if not halo:
+            os.environ["OSUF_GEMM_NOHALO"] = "1"
         try:
             ref = ops.gemm_nt(x, w, None, **kw)
             del os.environ["OSUF_GEMM_NO8P"]

@@ -22,11 +22,14 @@ def run(x, w, out, p8, taps=1, L=None):
         ops.gemm_nt(x, w, None, taps=taps, lin=L, lout=L, stride=1, pad=taps // 2, out=out)
 
 
-os.environ["OSUF_GEMM_NOHALO"] = "1"          # the k = 3 rows compare the two plain kernels (same summation order)
 bad = 0
-for N, K, taps in SHAPES:
+# (N, K, taps, plain): plain = the k = 3 row compares the two PLAIN kernels (OSUF_GEMM_NOHALO); otherwise the two shared-panel kernels
+HALO = [(256, 256, 3, False), (512, 512, 3, False), (768, 768, 3, False), (1024, 1024, 3, False), (256, 512, 3, False), (1024, 2048, 3, False), (256, 64, 3, False)]
+for N, K, taps, plain in [(n_, k_, t_, True) for n_, k_, t_ in SHAPES] + HALO:
+    if plain: os.environ["OSUF_GEMM_NOHALO"] = "1"
+    else: os.environ.pop("OSUF_GEMM_NOHALO", None)
     m = M if N * K * taps <= 1024 * 2048 else M // 4
-    L = 4096
+    L = 4096 if K <= 256 else 1024
     x = torch.randn(m, K, device="cuda").bfloat16(); w = (torch.randn(taps, N, K, device="cuda") * 0.05).bfloat16()
     ref = torch.empty(m, N, device="cuda", dtype=torch.bfloat16); out = torch.empty_like(ref)
     run(x, w, ref, False, taps, L)
@@ -51,7 +54,7 @@ for N, K, taps in SHAPES:
     ksteps = K * taps // 64
     tiles = -(-m // 256) * -(-N // 256)
     rounds_ = -(-tiles // 256)
-    print(f"M={m:6d} N={N:5d} K={K:5d} taps={taps}  mismatches over {args.screen} launches: {diff:6d}   plain {t0 * 1e3:8.1f} us {fl / t0 / 1e9:6.0f} TF/s   "
+    print(f"M={m:6d} N={N:5d} K={K:5d} taps={taps}{' ' if plain else 'h'} mismatches over {args.screen} launches: {diff:6d}   plain {t0 * 1e3:8.1f} us {fl / t0 / 1e9:6.0f} TF/s   "
           f"8-phase {t1 * 1e3:8.1f} us {fl / t1 / 1e9:6.0f} TF/s  ({t0 / t1:5.2f}x; min {min(ts[False]) * 1e3:.1f} / {min(ts[True]) * 1e3:.1f};  "
           f"us per K-step and tile round: {t0 * 1e3 / rounds_ / ksteps:.2f} -> {t1 * 1e3 / rounds_ / ksteps:.2f})", flush=True)
 print("TOTAL MISMATCHES", bad)
