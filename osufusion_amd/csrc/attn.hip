@@ -1966,12 +1966,15 @@ static int fused512_qsplit(int B, int N, int forced) {
   return sp;
 }
 static bool fused_mode_ok(int dq_mode) { return dq_mode >= OSUF_DQ_ATOMIC && dq_mode <= OSUF_DQ_ATOMIC_512A; }
-// the hand-placed loop (mqa_bwd_fused512a_kernel) walks the pairs two at a time and carries 32-bit byte offsets: whole query parts of an even
-// number of pairs, rows of at most 2^31 bytes per sample
+// the hand-placed loop (mqa_bwd_fused512a_kernel) walks the pairs two at a time and carries 32-bit byte offsets from the first row of a
+// sample's query part: whole query parts of an even number of pairs, and every running offset -- Q / dO requests (up to N rows of ldq / lddo
+// elements), dQ atomics (up to N + 32 rows of H * 64 floats: row bases + 16 rows of the second query half + the lane's 4 g4 rows), row
+// constants (H * N floats) -- below 2^31 (sign-safe).  tools/check_bwd512a_addresses.py replays the emitted text against exactly this guard.
 static bool fused512a_ok(const AttnArgs& a, int N) {
   const int nqb = N / 32;
   return (N % 512) == 0 && a.qsplit >= 1 && nqb % a.qsplit == 0 && (((nqb / a.qsplit) * a.H) % 2) == 0 &&
-         (long)N * a.ldq * 2 < (1L << 31) && (long)N * a.lddo * 2 < (1L << 31) && (long)a.H * D * 4 * 20 < (1L << 31);
+         (long)N * a.ldq * 2 < (1L << 31) && (long)N * a.lddo * 2 < (1L << 31) && ((long)N + 32) * a.H * D * 4 < (1L << 31) &&
+         (long)a.H * N * 4 < (1L << 31);
 }
 static long fused_dkv_ws_bytes(int B, int N, int qsplit, int dq_mode) {
   if (!fused_use512(B, N, dq_mode)) return osuf_mqa_bwd_dkv_workspace_bytes(B, N, qsplit);

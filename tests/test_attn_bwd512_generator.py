@@ -38,3 +38,26 @@ def test_a_broken_schedule_is_caught(tmp_path):
     bad.write_text(src.replace("for _ in range(6):", "for _ in range(0):", 1).replace("ROOT = Path(__file__).resolve().parent.parent", f"ROOT = Path({str(ROOT)!r})"))
     r = subprocess.run([sys.executable, str(bad), "--out", str(tmp_path / "x.inc")], capture_output=True, text=True)
     assert r.returncode != 0 and "dataflow differs" in r.stderr
+
+
+def test_every_global_address_of_the_loop_is_the_element_it_should_be():
+    """tools/check_bwd512a_addresses.py: the emitted text's scalar state machine and 32-bit running offsets, executed for all lanes from the
+    register values the kernel's prologue passes in, give exactly the wanted Q / dO / lse / delta / dQ element at every vector-memory
+    instruction -- for every shape family the launcher admits (H == 1, minimum trip count, odd H, query splits, strides at the 2^31 guard) --
+    and the statement clobbers everything it writes (m0).  Then three deliberately broken streams must be refused: a wrong dQ
+    head step, a request wrap delta taken from the wrong register, and a block wrap of the requests one head late."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import check_bwd512a_addresses as C
+    lines, clob = C.inc_lines(C.INC)
+    errs, checked = C.check_text(lines, clob, quick=True, verbose=False)
+    assert errs == 0 and checked > 100_000
+
+    def findings(mutate):
+        bad = mutate(list(lines))
+        assert bad != lines
+        sh = C.Shape(2, 1024, 4, 2, b=1, part=1)
+        return sum(len(C.run(bad, sh, w)[0]) for w in range(4))
+    assert findings(lambda L: [l.replace("s_movk_i32 s90, 256", "s_movk_i32 s90, 252") for l in L]) > 0
+    assert findings(lambda L: [l.replace("v_add_u32_e32 v252, s66, v252", "v_add_u32_e32 v252, s68, v252") for l in L]) > 0
+    assert findings(lambda L: [l.replace("s_sub_u32 s62, s61, 2", "s_sub_u32 s62, s61, 1") for l in L]) > 0
+    assert C.check_clobbers(lines, clob - {"m0"})                     # without the m0 clobber the check complains

@@ -84,3 +84,37 @@ def test_gemm_8phase_chip_filling_shapes_repeatable():
         finally:
             os.environ.pop("OSUF_GEMM_NO8P", None)
             os.environ.pop("OSUF_GEMM_NOHALO", None)
+
+
+@pytest.mark.parametrize("Bn,N,H,G,qsplit", [(2, 1024, 1, 1, 0), (2, 1024, 1, 1, 2), (1, 2048, 1, 1, 0), (1, 2048, 1, 1, 2),      # one query head per call
+                                             (2, 1024, 4, 4, 0),                                                                  # kv_heads == heads: four H = 1 launches
+                                             (1, 512, 2, 1, 16)])                                                                 # minimum trip count: two pairs per part
+def test_generated_attention_backward_one_head_paths(Bn, N, H, G, qsplit):
+    """the hand-placed 512-key sweep (mqa_bwd_fused512a_kernel, the default for N % 512 == 0) has dedicated H == 1 state --
+    `s_cmp_eq_u32 s61, 1`, one block step fewer for the request offsets, the first request advanced by the block-wrap delta -- that the H >= 2
+    cases never execute; per call H == 1 is what attn_kv_heads == attn_heads issues (unet.py:132-135).  Bit-identity of dK / dV with the
+    compiled 512-key sweep, dQ up to the order of its atomics, and both against autograd of the fp32 formula.  (tools/check_bwd512a_addresses.py
+    replays the same paths address by address on the CPU.)"""
+    D = 64
+    r = H // G
+    qkv = torch.randn(Bn, N, (H + 2 * G) * D, device=DEV).to(torch.bfloat16)
+    do = torch.randn(Bn, N, H * D, device=DEV).to(torch.bfloat16)
+    x = qkv.float().cpu().requires_grad_()
+    outs = []
+    for g in range(G):
+        q = x[..., g * r * D:(g + 1) * r * D].view(Bn, N, r, D).permute(0, 2, 1, 3)
+        k = x[..., (H + g) * D:(H + g + 1) * D][:, None]
+        v = x[..., (H + G + g) * D:(H + G + g + 1) * D][:, None]
+        s = (q @ k.transpose(-1, -2)) * D ** -0.5
+        outs.append((s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(Bn, N, r * D))
+    torch.cat(outs, -1).backward(do.float().cpu())
+    g_ref = x.grad.to(DEV)
+    o, lse = ops.mqa_fwd(qkv, Bn, N, H, D, torch.bfloat16, D ** -0.5, kv_heads=G)
+    got = ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5, variant=ops.ATTN_FUSED512A, qsplit=qsplit, kv_heads=G)
+    ref = ops.mqa_bwd(qkv, o, do, lse, Bn, N, H, D, D ** -0.5, variant=ops.ATTN_FUSED512, qsplit=qsplit, kv_heads=G)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got[..., H * D:], ref[..., H * D:])
+    e_dq = ((got[..., :H * D] - ref[..., :H * D]).norm() / ref[..., :H * D].norm()).item()
+    e = ((got - g_ref).norm() / g_ref.norm()).item()
+    report(f"attn_bwd512a_one_head/B{Bn}_N{N}_H{H}_G{G}_qs{qsplit}", dq_vs_compiled=e_dq, vs_autograd=e)
+    assert e_dq < 1e-5 and e < 1e-2

@@ -859,7 +859,7 @@ def main():
         f.write('  ""\n')
         cl = ", ".join(f'"v{i}"' for i in range(64, 192)) + ", " + ", ".join(f'"a{i}"' for i in range(256))
         sc = ", ".join(f'"s{i}"' for i in (SD128, SDN4, SDQS, SHS, SHD, SMASK, SMASK + 1) + tuple(range(SROW, SROW + 8)) + (SC2, SC2 + 1))
-        f.write(f'#define OSUF_BWD512A_CLOBBERS "memory", "vcc", "scc", {sc}, {cl}\n')
+        f.write(f'#define OSUF_BWD512A_CLOBBERS "memory", "vcc", "scc", "m0", {sc}, {cl}\n')     # m0: the LDS-DMA destinations
     if "--stats" in sys.argv:
         per_pair = {k: v / 2 for k, v in loop_count.items() if k not in ("init", "fini")}
         tot = sum(v for k, v in per_pair.items() if not k.startswith("mfma"))
