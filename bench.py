@@ -101,14 +101,19 @@ def build_model(device, dim_h: int):
 def cpu_baseline(model, length: int, thread_counts):
     """The oracle (CPU restatement of the reference, pinned to its golden vectors) on this box's host cores: one fwd+bwd
     of the same full-size model at B=1, L=length, fp32 params + bf16 SDPA exactly as the reference computes on CPU.  Timed at
-    every thread count given; `value` is the FASTEST of them (the CPU's best), the others are listed under `other_thread_counts`."""
-    runs = [_cpu_baseline_at(model, length, n, warm=3 if i == 0 else 1, timed=5 if i == 0 else 3) for i, n in enumerate(thread_counts)]
+    every thread count given, smallest first (BASELINE.md section 3's 3 warm-ups + 5 timed iterations); a larger count that is already
+    slower on its first iteration (a 1-GPU box of the pool grants ~16 CPUs: more threads than that only oversubscribe them) is
+    recorded from that one iteration and not pursued.  `value` is the FASTEST count (the CPU's best); the others are listed."""
+    runs = []
+    for n in sorted(thread_counts):
+        limit = 1.25 * runs[0]["seconds_per_sample"] if runs else None
+        runs.append(_cpu_baseline_at(model, length, n, give_up_above=limit))
     best = max(runs, key=lambda r: r["value"])
     best["other_thread_counts"] = [dict(cores=r["cores"], value=r["value"], sample=r["sample"]) for r in runs if r is not best]
     return best
 
 
-def _cpu_baseline_at(model, length: int, threads: int, warm: int = 3, timed: int = 5):
+def _cpu_baseline_at(model, length: int, threads: int, warm: int = 3, timed: int = 5, give_up_above=None):
     from oracle import diffusion_oracle as DO
     from oracle import unet_oracle as O
     torch.set_num_threads(threads)
@@ -117,7 +122,7 @@ def _cpu_baseline_at(model, length: int, threads: int, warm: int = 3, timed: int
     p = {k: v.detach().float().cpu().clone().requires_grad_() for k, v in model.state_dict().items()}
     x, a, c, noise, t = synth_batch(0, "cpu", 1, length)
     times = []
-    # 3 warm-ups, 5 timed iterations, median (~25 s of CPU work) at the first thread count
+    gave_up = False
     for it in range(warm + timed):
         for v in p.values():
             v.grad = None
@@ -126,9 +131,16 @@ def _cpu_baseline_at(model, length: int, threads: int, warm: int = 3, timed: int
         loss.backward()
         times.append(time.perf_counter() - t0)
         print(f"[bench] cpu_baseline: iteration {it} fwd+bwd {times[-1]:.1f} s", file=sys.stderr, flush=True)
-    dt = sorted(times[warm:])[timed // 2]
+        if give_up_above is not None and it == 1 and min(times) > give_up_above:
+            gave_up = True                                 # second iteration (the first pays one-time allocations) and still slower: oversubscribed
+            break
+    if gave_up:
+        dt, how = min(times), f"best of {len(times)} iterations, not pursued: slower than the smaller thread count"
+    else:
+        dt, how = sorted(times[warm:])[timed // 2], f"median of {timed} after {warm} warm-ups"
     return dict(value=1.0 / (BATCH * dt), unit="denoise-steps/sec (B=32, linear extrapolation from B=1)", cores=threads, cpu=cpu_model(), kind="port",
-                sample=f"fwd+bwd of the full UNet at B=1, L={length}: {dt:.2f} s/sample (median of {timed} after {warm} warm-ups; oracle/, "
+                seconds_per_sample=round(dt, 3),
+                sample=f"fwd+bwd of the full UNet at B=1, L={length}: {dt:.2f} s/sample ({how}; oracle/, "
                        f"fp32 + bf16 SDPA as the reference computes on CPU)")
 
 
@@ -252,7 +264,7 @@ def host_thread_counts():
     """Thread counts the CPU baseline is timed at: every physical core of the affinity mask, and the
     16-thread share a 1-GPU box of the pool is entitled to (a cgroup quota, where there is one, makes the smaller count the faster)."""
     n = physical_cores_in_affinity()
-    return sorted({n, min(n, 16)}, reverse=True)
+    return sorted({n, min(n, 16)})
 
 
 def main() -> None:
@@ -447,9 +459,11 @@ def main() -> None:
             if "error" not in out["fp32_modes"]:
                 out.update(out.pop("fp32_modes"))
                 out["fp32_exact_mode_ms_per_step"] = out["fp32_mode_ms_per_step"]
-            out["parity_note"] = ("bf16 (timed) is 0.9-1.3e-2 rel-L2 from the fp32 oracle = the oracle's own bf16-vs-fp32 distance; both fp32 modes "
-                                  "are held to 1e-3 at this size by tests/test_full_size.py (forward of two samples and all 1,239 gradients of one "
-                                  "sample, each run with set_f32_matmul('exact') and ('x3')): fp32x3_mode = split-bf16 GEMMs, fp32_mode = f32 MFMA")
+            out["parity_note"] = ("bf16 (timed) vs the fp32 golden of the imported reference (unet_mid): output 8.5e-3, flat gradient 6.6e-3 -- the reference's OWN "
+                                  "bf16 autocast (trainer.py:295,374; tests/golden/unet_mid_autocast.npz) sits at 1.08e-2 / 8.0e-3 from its fp32 run, per-parameter "
+                                  "HIP / reference ratio max 1.16, median 0.82 (tests/test_hip_parity.py::test_unet_bf16_vs_reference_autocast); both fp32 modes are "
+                                  "held to 1e-3 at full size by tests/test_full_size.py (forward of two samples and all 1,239 gradients of one sample, each with "
+                                  "set_f32_matmul('exact') and ('x3')): fp32x3_mode = split-bf16 GEMMs, fp32_mode = f32 MFMA")
         if world == 1 and not args.no_sampler and not args.lora and full:
             print("[bench] secondary: DDIM sample at config 4's size ...", file=sys.stderr, flush=True)
             guarded("secondary", lambda: sampler_secondary(model, device))
