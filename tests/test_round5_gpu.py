@@ -41,12 +41,19 @@ def test_gemm_8phase_kernel_bit_exact(monkeypatch, kind, k, L, Cin):
         stats = torch.zeros(B, 2, dtype=torch.float64, device=DEV)
         y, pre = Fn.conv_forward(x, w, bias, Fn.PackCache(), kind, None, act=1, residual=res, rscale=rscale, stats=stats, want_pre=True)
         dx = Fn.conv_dgrad(y, w, Fn.PackCache(), kind, L, residual=x)
-        outs[name] = (y.float(), pre.float(), stats.clone(), dx.float())
+        # the launches without residual / pre-activation copy: transposed accumulators + gemm_big_epilogue_tr (bias, SiLU, GroupNorm sums)
+        stats2 = torch.zeros(B, 2, dtype=torch.float64, device=DEV)
+        y2 = Fn.conv_forward(x, w, bias, Fn.PackCache(), kind, None, act=1, stats=stats2)
+        y3 = Fn.conv_forward(x, w, None, Fn.PackCache(), kind, None)
+        dx2 = Fn.conv_dgrad(y, w, Fn.PackCache(), kind, L)
+        outs[name] = (y.float(), pre.float(), stats.clone(), dx.float(), y2.float(), y3.float(), dx2.float(), stats2.clone())
     monkeypatch.delenv("OSUF_GEMM_BIG_MIN_TILES")
     monkeypatch.delenv("OSUF_GEMM_NO8P", raising=False)
-    for a, b_ in zip(outs["p8"][:2] + outs["p8"][3:], outs["plain"][:2] + outs["plain"][3:]):
+    for a, b_ in zip(outs["p8"][:2] + outs["p8"][3:7], outs["plain"][:2] + outs["plain"][3:7]):
         assert torch.equal(a, b_)
     assert torch.allclose(outs["p8"][2], outs["plain"][2], rtol=1e-6)          # LDS float atomics inside a tile: order only
+    assert torch.allclose(outs["p8"][7], outs["plain"][7], rtol=1e-6)
+    assert torch.equal(outs["p8"][5], outs["small"][5])                        # no activation: also the 128 x 128 kernel's output bit for bit
     assert torch.equal(outs["p8"][1], outs["small"][1])
     xq, wq = x.float(), w.to(torch.bfloat16).float()
     if kind == "same":
