@@ -13,9 +13,16 @@ M = 131072
 SHAPES = [(256, 256, 1), (1152, 256, 1), (1024, 256, 1), (256, 1024, 1), (256, 64, 1), (256, 128, 1), (512, 512, 1), (1024, 1024, 1), (1024, 2048, 1), (256, 256, 3), (768, 768, 3)]
 
 
+VAR = os.environ.get("CHECK_VAR", "OSUF_GEMM_NO8P")      # the switch under test: "plain" column = switch set (NO8P) / for other switches: unset
+
+
 def run(x, w, out, p8, taps=1, L=None):
-    if p8: os.environ.pop("OSUF_GEMM_NO8P", None)
-    else: os.environ["OSUF_GEMM_NO8P"] = "1"
+    if VAR == "OSUF_GEMM_NO8P":
+        if p8: os.environ.pop("OSUF_GEMM_NO8P", None)
+        else: os.environ["OSUF_GEMM_NO8P"] = "1"
+    else:
+        if p8: os.environ[VAR] = "1"
+        else: os.environ.pop(VAR, None)
     if taps == 1:
         ops.gemm_nt(x, w, None, out=out)
     else:
