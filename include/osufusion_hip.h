@@ -144,12 +144,21 @@ long osuf_gca_bwd_apply_workspace_bytes(int M, int C);
  *           the q/k/v -> bf16 casts of Attend.forward (attention.py:87-92) */
 int osuf_rope_cast(int dtype, const void* in, long ld_in, void* out_bf16, long ld_out, const float* cos_tab, const float* sin_tab,
                    int M, int N, int n_rot_heads, int n_heads_total, int head_dim, hipStream_t stream);
+/* as osuf_rope_cast (head_dim 64), and the first n_q_heads heads -- the queries -- are multiplied by q_mul before their bf16 rounding: with
+ * q_mul = scale * log2(e) the softmax scale of attention.py:94-99 rides the one rounding the reference's bf16 cast (attention.py:87-92) performs
+ * anyway, and osuf_mqa_fwd_qs / osuf_mqa_bwd_fused_qs take Qs K^T straight as log2-domain scores. */
+int osuf_rope_cast_qs(int dtype, const void* in, long ld_in, void* out_bf16, long ld_out, const float* cos_tab, const float* sin_tab,
+                      int M, int N, int n_rot_heads, int n_heads_total, int head_dim, float q_mul, int n_q_heads, hipStream_t stream);
 int osuf_rope_bwd(int dtype, const float* in, long ld_in, void* out, long ld_out, const float* cos_tab, const float* sin_tab,
                   int M, int N, int n_rot_heads, int n_heads_total, int head_dim, hipStream_t stream);
 /* replaces: the GQA repeat (modules/unet.py:135) + F.scaled_dot_product_attention (attention.py:94-99) and its backward.
  * q/k/v/dout are bf16; o is written bf16-rounded in o_dtype; lse2 = log2-domain logsumexp [B][H][N]. */
 int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
                  float* lse2, int B, int H, int N, int head_dim, float scale, hipStream_t stream);
+/* osuf_mqa_fwd for queries pre-scaled by scale * log2(e) (osuf_rope_cast_qs); same outputs, same lse2 convention; head_dim 64.
+ * replaces: F.scaled_dot_product_attention at attention.py:94-99 (as osuf_mqa_fwd). */
+int osuf_mqa_fwd_qs(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
+                    float* lse2, int B, int H, int N, int head_dim, float scale, hipStream_t stream);
 /* Attend(q, k, v, attn_mask) (attention.py:77-99): the reference casts the mask to bf16 and passes it to SDPA as an additive bias of
  * the scaled scores (so a bool mask adds 1.0 / 0.0 -- kept).  mask: bf16, element strides over (batch, head, query, key), 0 for a
  * broadcast dimension.  Inference only (no backward entry point); all head dims go through the generic kernel.
@@ -188,6 +197,14 @@ int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long ldk, const v
                        const float* lse2, const float* delta, void* dq, long lddq, void* dk, void* dv, long lddk, int B, int H,
                        int N, int head_dim, float scale, int out_dtype, const float* rope_cos, const float* rope_sin,
                        float* workspace, long workspace_bytes, int qsplit, int dq_mode, hipStream_t stream);
+/* osuf_mqa_bwd_fused for queries pre-scaled by c = scale * log2(e) (q from osuf_rope_cast_qs, lse2 from osuf_mqa_fwd_qs): p = exp2(Qs K^T - lse2)
+ * without a multiply (the generated 512-key loop drops 64 vector instructions per (head, 32-query block) pair); dq is still the gradient of the
+ * UN-scaled rotated q (scale dS K), dk = (scale / c) dS^T Qs.  Same workspace, same arguments.
+ * replaces: the backward of attention.py:94-99 under unet.py:125-141 (as osuf_mqa_bwd_fused). */
+int osuf_mqa_bwd_fused_qs(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
+                          const float* lse2, const float* delta, void* dq, long lddq, void* dk, void* dv, long lddk, int B, int H,
+                          int N, int head_dim, float scale, int out_dtype, const float* rope_cos, const float* rope_sin,
+                          float* workspace, long workspace_bytes, int qsplit, int dq_mode, hipStream_t stream);
 long osuf_mqa_bwd_fused_workspace_bytes(int B, int H, int N, int out_dtype, int qsplit, int dq_mode);
 
 /* ---- layout / scheduler / optimizer (elementwise.hip) ----------------------------------------------------------

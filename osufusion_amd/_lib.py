@@ -40,14 +40,17 @@ SIGNATURES = {
     "osuf_gca_bwd_apply": [I, P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, P, P, P, L, P],
     "osuf_gca_bwd_apply_workspace_bytes": [I, I],
     "osuf_rope_cast": [I, P, L, P, L, P, P, I, I, I, I, I, P],
+    "osuf_rope_cast_qs": [I, P, L, P, L, P, P, I, I, I, I, I, F, I, P],
     "osuf_rope_bwd": [I, P, L, P, L, P, P, I, I, I, I, I, P],
     "osuf_mqa_fwd": [P, L, P, L, P, L, P, L, I, P, I, I, I, I, F, P],
+    "osuf_mqa_fwd_qs": [P, L, P, L, P, L, P, L, I, P, I, I, I, I, F, P],
     "osuf_mqa_fwd_masked": [P, L, P, L, P, L, P, L, I, P, P, L, L, L, L, I, I, I, I, F, P],
     "osuf_attn_delta": [P, L, P, L, I, P, I, I, I, I, P],
     "osuf_mqa_bwd_dq": [P, L, P, L, P, L, P, L, P, P, P, L, I, I, I, I, F, I, P, P, I, P],
     "osuf_mqa_bwd_dkv": [P, L, P, L, P, L, P, L, P, P, P, P, L, I, I, I, I, F, I, P, P, P, L, I, I, P],
     "osuf_mqa_bwd_dkv_workspace_bytes": [I, I, I],
     "osuf_mqa_bwd_fused": [P, L, P, L, P, L, P, L, P, P, P, L, P, P, L, I, I, I, I, F, I, P, P, P, L, I, I, P],
+    "osuf_mqa_bwd_fused_qs": [P, L, P, L, P, L, P, L, P, P, P, L, P, P, L, I, I, I, I, F, I, P, P, P, L, I, I, P],
     "osuf_mqa_bwd_fused_workspace_bytes": [I, I, I, I, I, I],
     "osuf_ncl_to_rows": [I, P, P, L, I, I, I, I, I, P],
     "osuf_rows_to_ncl": [I, P, L, P, I, I, I, P],

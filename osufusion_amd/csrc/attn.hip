@@ -120,6 +120,8 @@ struct AttnArgs {
   const float* rcos; const float* rsin;         // [N][32] RoPE tables: when set, dQ / dK are stored as gradients of the UN-rotated q / k
   int B, H, N;
   float scale;
+  float cexp, kmul;                             // exponent multiplier of S (scale * log2 e; 1 when q arrives pre-scaled by it: the *_qs entry points)
+                                                // and the multiplier of the dK sums (scale; scale / cexp = 1 / log2 e for pre-scaled q)
   int qsplit;                                   // dK/dV: > 1 = the query range is cut into qsplit parts (short sequences: more workgroups),
   float* wsk; float* wsv;                       //        per-part partial sums in [qsplit][B*N][64] workspaces, summed by dkv_finish_kernel
   const bf16_t* mask; long mask_b, mask_h, mask_q, mask_k;   // osuf_mqa_fwd_masked: additive bf16 score bias, element strides (0 = broadcast)
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
   const int h = active ? vb % a.H : 0, pb = active ? vb / a.H : 0;
   const int qrow = pb * 32 + lr;
   const bool qok = active && qrow < a.N;
-  const float c = a.scale * kLog2e;
+  const float c = a.cexp;
 
   // Q tile of this wave: 32 rows x 128 B in a wave-private LDS slice behind the K/V ring (re-read once per k-step).  Keeping
   // the 16 fragment registers live across the loop pushed the kernel over 128 VGPRs; at <= 128 four waves per SIMD fit
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(NW * 64) void mqa_bwd_dq_kernel(AttnArgs a) {
   const int h = active ? vb % a.H : 0, pb = active ? vb / a.H : 0;
   const int qrow = pb * 32 + lr;
   const bool qok = active && qrow < a.N;
-  const float c = a.scale * kLog2e;
+  const float c = a.cexp;
 
   bf16x8 qf[4], dof[4];
   {
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_dq_pipe_kernel(AttnArgs a) {
   const int h = active ? vb % a.H : 0, pb = active ? vb / a.H : 0;
   const int qrow = pb * 32 + lr;
   const bool qok = active && qrow < a.N;
-  const float c = a.scale * kLog2e;
+  const float c = a.cexp;
 
   bf16x8 qf[4], dof[4];
   {
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(NW * 64) void mqa_bwd_dkv_kernel(AttnArgs a) {
   if (b >= a.B) return;
   const int key = kb * (32 * NW) + wave * 32 + lr;
   const bool kok = key < a.N;
-  const float c = a.scale * kLog2e;
+  const float c = a.cexp;
   const int nqb = (a.N + 31) >> 5;
   const int niter = nqb * a.H;
 
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(NW * 64) void mqa_bwd_dkv_kernel(AttnArgs a) {
     if (DBG != 2) __syncthreads();
   }
   if (kok) {
-    store_grad(a.dk, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dk, a.scale, a.rcos, a.rsin, key, lh);
+    store_grad(a.dk, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dk, a.kmul, a.rcos, a.rsin, key, lh);
     store_grad(a.dv, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dv, 1.f, nullptr, nullptr, key, lh);
   }
 }
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_pipe_kernel(AttnArgs a) {
   if (b >= a.B) return;
   const int key = kb * (32 * NW) + wave * 32 + lr;
   const bool kok = key < a.N;
-  const float c = a.scale * kLog2e;
+  const float c = a.cexp;
   const int nqb = (a.N + 31) >> 5;
   const int qb_per = (nqb + a.qsplit - 1) / a.qsplit;
   const int qb_begin = part * qb_per, qb_end = min(nqb, qb_begin + qb_per);
@@ -838,7 +840,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_dkv_pipe_kernel(AttnArgs a) {
     store_grad_row(a.wsk + prow * D, dk, 1.f, nullptr, nullptr, lh);
     store_grad_row(a.wsv + prow * D, dv, 1.f, nullptr, nullptr, lh);
   } else if (kok) {
-    store_grad(a.dk, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dk, a.scale, a.rcos, a.rsin, key, lh);
+    store_grad(a.dk, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dk, a.kmul, a.rcos, a.rsin, key, lh);
     store_grad(a.dv, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dv, 1.f, nullptr, nullptr, key, lh);
   }
 }
@@ -886,7 +888,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_fused_kernel(AttnArgs a, float* d
   if (b >= a.B) return;
   const int key = kb * (32 * NW) + wave * 32 + lr;
   const bool kok = key < a.N;
-  const float c = a.scale * kLog2e;
+  const float c = a.cexp;
   const int nqb = (a.N + 31) >> 5;
   const int qb_per = (nqb + a.qsplit - 1) / a.qsplit;
   const int qb_begin = part * qb_per, qb_end = min(nqb, qb_begin + qb_per);
@@ -1079,7 +1081,7 @@ __global__ __launch_bounds__(512) void mqa_bwd_fused_kernel(AttnArgs a, float* d
     store_grad_row(a.wsk + prow * D, dk, 1.f, nullptr, nullptr, lh);
     store_grad_row(a.wsv + prow * D, dv, 1.f, nullptr, nullptr, lh);
   } else if (kok) {
-    store_grad(a.dk, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dk, a.scale, a.rcos, a.rsin, key, lh);
+    store_grad(a.dk, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dk, a.kmul, a.rcos, a.rsin, key, lh);
     store_grad(a.dv, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dv, 1.f, nullptr, nullptr, key, lh);
   }
 }
@@ -1160,7 +1162,7 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512_kernel(AttnArgs a, fl
   const int b = (qid / nkb) * 8 + xcd;
   const int kb = qid % nkb;
   if (b >= a.B) return;
-  const float c = a.scale * kLog2e;
+  const float c = a.cexp;
   const int nqb = a.N >> 5;
   const int qb_per = (nqb + a.qsplit - 1) / a.qsplit;
   const int qb_begin = part * qb_per, qb_end = min(nqb, qb_begin + qb_per);
@@ -1423,7 +1425,7 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512_kernel(AttnArgs a, fl
       store_grad_row(a.wsk + prow * D, dk[t], 1.f, nullptr, nullptr, lh);
       store_grad_row(a.wsv + prow * D, dv[t], 1.f, nullptr, nullptr, lh);
     } else if (key < a.N) {
-      store_grad(a.dk, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dk[t], a.scale, a.rcos, a.rsin, key, lh);
+      store_grad(a.dk, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dk[t], a.kmul, a.rcos, a.rsin, key, lh);
       store_grad(a.dv, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dv[t], 1.f, nullptr, nullptr, key, lh);
     }
   }
@@ -1438,9 +1440,11 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512_kernel(AttnArgs a, fl
 // Whole 512-key blocks only (N % 512 == 0), hence niter = (N / 32 / qsplit) * H is even: the loop is unrolled by two.
 // ------------------------------------------------------------------------------------------------------
 #include "attn_bwd512_asm.inc"
+#include "attn_bwd512qs_asm.inc"      // the same loop for queries pre-scaled by c (tools/gen_attn_bwd512.py --qs): no v_mul of the scores
 typedef __attribute__((ext_vector_type(32))) uint32_t u32x32;
 typedef __attribute__((ext_vector_type(8))) uint32_t u32x8;
 typedef __attribute__((ext_vector_type(32))) float f32x32;
+template <bool QS>
 __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512a_kernel(AttnArgs a, float* dq32) {
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][Q 4K | dO 4K | -lse/c 128 | -delta 128] | K image 64K | [2] dS image 32K
   constexpr int kStage = 4096 + 4096 + 256;
@@ -1455,7 +1459,12 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512a_kernel(AttnArgs a, f
   const int b = (qid / nkb) * 8 + xcd;
   const int kb = qid % nkb;
   if (b >= a.B) return;
-  const float c = a.scale * kLog2e;
+  float c = a.cexp;
+  // c is pinned into a VECTOR register before the two v_readfirstlane statements below.  With the kernel argument left in its SGPR (hipcc then
+  // copies it by a v_mov right in front of the inline-asm v_readfirstlane) the non-QS loop ran with wrong row constants -- every gradient
+  // ~0.6 N times too large -- in two builds that differ in nothing but this line (tools/check_bwd512a.py; the printed c and -1/c were right,
+  // the emitted instruction streams equal up to register names: the mechanism was NOT identified; tests/test_asm_hazards.py refuses that shape)
+  asm volatile("" : "+v"(c));
   const int nqb = a.N >> 5;
   const int qb_per = nqb / a.qsplit;
   const int qb_begin = part * qb_per;
@@ -1550,13 +1559,23 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512a_kernel(AttnArgs a, f
   const uint32_t m0base = __builtin_amdgcn_readfirstlane(sb + (uint32_t)wave * 1024u);
   __syncthreads();
   f32x32 acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7;                                    // dK^T tiles 0..3, dV^T tiles 0..3 (the loop's a[0:255], copied to v[0:255] at its end)
+  if constexpr (QS) {
+  asm volatile(OSUF_BWD512AQS_ASM
+                 : "={v[0:31]}"(acc0), "={v[32:63]}"(acc1), "={v[64:95]}"(acc2), "={v[96:127]}"(acc3), "={v[128:159]}"(acc4), "={v[160:191]}"(acc5),
+                   "={v[192:223]}"(acc6), "={v[224:255]}"(acc7), "+{s60}"(cnt), "+{s63}"(srem)
+                 : "{v[0:31]}"(vf0), "{v[32:63]}"(vf1), "{v[224:255]}"(adr), "{s[48:49]}"(pq), "{s[50:51]}"(pdo), "{s[52:53]}"(pls), "{s[54:55]}"(pdl),
+                   "{s[56:57]}"(pdq), "{s61}"(hh), "{s65}"(n4), "{s66}"((uint32_t)wq), "{s68}"((uint32_t)wdo), "{s70}"((uint32_t)wls), "{s72}"((uint32_t)wdq),
+                   "{s74}"(cbits), "{s75}"(nrc), "{s76}"(m0base), "{s77}"(skof), "{s80}"(rowb)
+                 : OSUF_BWD512AQS_CLOBBERS);
+  } else {
   asm volatile(OSUF_BWD512A_ASM
-               : "={v[0:31]}"(acc0), "={v[32:63]}"(acc1), "={v[64:95]}"(acc2), "={v[96:127]}"(acc3), "={v[128:159]}"(acc4), "={v[160:191]}"(acc5),
-                 "={v[192:223]}"(acc6), "={v[224:255]}"(acc7), "+{s60}"(cnt), "+{s63}"(srem)
-               : "{v[0:31]}"(vf0), "{v[32:63]}"(vf1), "{v[224:255]}"(adr), "{s[48:49]}"(pq), "{s[50:51]}"(pdo), "{s[52:53]}"(pls), "{s[54:55]}"(pdl),
-                 "{s[56:57]}"(pdq), "{s61}"(hh), "{s65}"(n4), "{s66}"((uint32_t)wq), "{s68}"((uint32_t)wdo), "{s70}"((uint32_t)wls), "{s72}"((uint32_t)wdq),
-                 "{s74}"(cbits), "{s75}"(nrc), "{s76}"(m0base), "{s77}"(skof), "{s80}"(rowb)
-               : OSUF_BWD512A_CLOBBERS);
+                 : "={v[0:31]}"(acc0), "={v[32:63]}"(acc1), "={v[64:95]}"(acc2), "={v[96:127]}"(acc3), "={v[128:159]}"(acc4), "={v[160:191]}"(acc5),
+                   "={v[192:223]}"(acc6), "={v[224:255]}"(acc7), "+{s60}"(cnt), "+{s63}"(srem)
+                 : "{v[0:31]}"(vf0), "{v[32:63]}"(vf1), "{v[224:255]}"(adr), "{s[48:49]}"(pq), "{s[50:51]}"(pdo), "{s[52:53]}"(pls), "{s[54:55]}"(pdl),
+                   "{s[56:57]}"(pdq), "{s61}"(hh), "{s65}"(n4), "{s66}"((uint32_t)wq), "{s68}"((uint32_t)wdo), "{s70}"((uint32_t)wls), "{s72}"((uint32_t)wdq),
+                   "{s74}"(cbits), "{s75}"(nrc), "{s76}"(m0base), "{s77}"(skof), "{s80}"(rowb)
+                 : OSUF_BWD512A_CLOBBERS);
+  }
   const f32x32 dkv[8] = {acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7};
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -1569,7 +1588,7 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512a_kernel(AttnArgs a, f
       store_grad_row(a.wsk + prow * D, dk, 1.f, nullptr, nullptr, lh);
       store_grad_row(a.wsv + prow * D, dv, 1.f, nullptr, nullptr, lh);
     } else {
-      store_grad(a.dk, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dk, a.scale, a.rcos, a.rsin, key, lh);
+      store_grad(a.dk, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dk, a.kmul, a.rcos, a.rsin, key, lh);
       store_grad(a.dv, a.lddk, (long)b * a.N + key, 0, a.g_bf16, dv, 1.f, nullptr, nullptr, key, lh);
     }
   }
@@ -1707,7 +1726,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* dout, lon
 // ------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void rope_cast_kernel(const T* in, long ld_in, bf16_t* out, long ld_out, const float* cosb,
-                                                        const float* sinb, int M, int N, int n_rot_heads, int n_heads_total) {
+                                                        const float* sinb, int M, int N, int n_rot_heads, int n_heads_total,
+                                                        float qmul, int n_q_heads) {
   // one thread: 8 columns d0..d0+7 (d0 < 32) of one head and their partners d0+32..; 4 threads per (row, head)
   const long total = (long)M * n_heads_total * 4;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -1729,6 +1749,10 @@ __global__ __launch_bounds__(256) void rope_cast_kernel(const T* in, long ld_in,
         const float a2 = x2[e] * cs[e] + x1[e] * sn[e];
         x1[e] = a1; x2[e] = a2;
       }
+    }
+    if (hd < n_q_heads) {                                       // osuf_rope_cast_qs: the softmax scale rides the queries' one bf16 rounding
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x1[e] *= qmul; x2[e] *= qmul; }
     }
     store8(out + m * ld_out + hd * D + sub * 8, x1);
     store8(out + m * ld_out + hd * D + 32 + sub * 8, x2);
@@ -1779,13 +1803,26 @@ static inline int ew_grid(long total_threads) {
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // head dims served by the generic kernels of attn_generic.hpp (64 has the tuned kernels of this file): padded tile width, 0 = unsupported
 static int gen_dp(int head_dim) { return head_dim == 16 || head_dim == 32 ? 32 : head_dim == 128 ? 128 : 0; }
+static int mqa_fwd_impl(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
+                        float* lse2, int B, int H, int N, int head_dim, float scale, bool qs, hipStream_t stream);
 extern "C" int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
                             float* lse2, int B, int H, int N, int head_dim, float scale, hipStream_t stream) {
+  return mqa_fwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, o_dtype, lse2, B, H, N, head_dim, scale, false, stream);
+}
+// q holds the rotated queries ALREADY multiplied by scale * log2 e (osuf_rope_cast_qs): the scores leave the MFMA chain in the log2 domain
+extern "C" int osuf_mqa_fwd_qs(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
+                               float* lse2, int B, int H, int N, int head_dim, float scale, hipStream_t stream) {
+  if (head_dim != D) return OSUF_EUNSUPPORTED;
+  return mqa_fwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, o_dtype, lse2, B, H, N, head_dim, scale, true, stream);
+}
+static int mqa_fwd_impl(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
+                        float* lse2, int B, int H, int N, int head_dim, float scale, bool qs, hipStream_t stream) {
   if (head_dim != D && !gen_dp(head_dim)) return OSUF_EUNSUPPORTED;
   if (B <= 0 || H <= 0 || N <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || !al16(q) || !al16(k) || !al16(v) || !al16(o)) return OSUF_EINVAL;
   AttnArgs a = {};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
-  a.o = o; a.ldo = ldo; a.o_is_f32 = o_dtype == OSUF_DT_F32; a.lse2 = lse2; a.B = B; a.H = H; a.N = N; a.scale = scale;
+  a.o = o; a.ldo = ldo; a.o_is_f32 = o_dtype == OSUF_DT_F32; a.lse2 = lse2; a.B = B; a.H = H; a.N = N; a.scale = scale; a.cexp = scale * kLog2e; a.kmul = scale;
+  if (qs) a.cexp = 1.f;
   const int nvb = ((N + 31) / 32) * H;
   if (head_dim != D) {
     const dim3 grid((nvb + 3) / 4, B);
@@ -1807,7 +1844,7 @@ extern "C" int osuf_mqa_fwd_masked(const void* q, long ldq, const void* k, long 
     return OSUF_EINVAL;
   AttnArgs a = {};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
-  a.o = o; a.ldo = ldo; a.o_is_f32 = o_dtype == OSUF_DT_F32; a.lse2 = lse2; a.B = B; a.H = H; a.N = N; a.scale = scale;
+  a.o = o; a.ldo = ldo; a.o_is_f32 = o_dtype == OSUF_DT_F32; a.lse2 = lse2; a.B = B; a.H = H; a.N = N; a.scale = scale; a.cexp = scale * kLog2e; a.kmul = scale;
   a.mask = (const bf16_t*)mask; a.mask_b = mask_b; a.mask_h = mask_h; a.mask_q = mask_q; a.mask_k = mask_k;
   const int nvb = ((N + 31) / 32) * H;
   const dim3 grid((nvb + 3) / 4, B);
@@ -1826,7 +1863,7 @@ static int fill_bwd_args(AttnArgs& a, const void* q, long ldq, const void* k, lo
   a = AttnArgs{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
   a.lse2 = const_cast<float*>(lse2); a.dout = (const bf16_t*)dout; a.lddo = lddo; a.delta = delta;
-  a.B = B; a.H = H; a.N = N; a.scale = scale; a.qsplit = 1;
+  a.B = B; a.H = H; a.N = N; a.scale = scale; a.cexp = scale * kLog2e; a.kmul = scale; a.qsplit = 1;
   return OSUF_OK;
 }
 
@@ -1930,8 +1967,8 @@ extern "C" int osuf_mqa_bwd_dkv(const void* q, long ldq, const void* k, long ldk
     hipLaunchKernelGGL(mqa_bwd_dkv_pipe_kernel, dim3(grid.x * a.qsplit), dim3(512), 3 * (4096 + 4096 + 256), stream, a);
     const long M = (long)B * N;
     const unsigned fb = (unsigned)((M * 32 + 255) / 256);
-    if (a.g_bf16) hipLaunchKernelGGL(dkv_finish_kernel<bf16_t>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (bf16_t*)dk, (bf16_t*)dv, lddk, M, N, scale, rope_cos, rope_sin);
-    else hipLaunchKernelGGL(dkv_finish_kernel<float>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (float*)dk, (float*)dv, lddk, M, N, scale, rope_cos, rope_sin);
+    if (a.g_bf16) hipLaunchKernelGGL(dkv_finish_kernel<bf16_t>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (bf16_t*)dk, (bf16_t*)dv, lddk, M, N, a.kmul, rope_cos, rope_sin);
+    else hipLaunchKernelGGL(dkv_finish_kernel<float>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (float*)dk, (float*)dv, lddk, M, N, a.kmul, rope_cos, rope_sin);
   } else {
     hipLaunchKernelGGL(mqa_bwd_dkv_pipe_kernel, grid, dim3(512), 3 * (4096 + 4096 + 256), stream, a);
   }
@@ -1986,13 +2023,34 @@ extern "C" long osuf_mqa_bwd_fused_workspace_bytes(int B, int H, int N, int out_
   return fused_dq_bytes(B, H, N, out_dtype, dq_mode) + fused_dkv_ws_bytes(B, N, qsplit, dq_mode);
 }
 
+static int mqa_bwd_fused_impl(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
+                              const float* lse2, const float* delta, void* dq, long lddq, void* dk, void* dv, long lddk, int B, int H,
+                              int N, int head_dim, float scale, int out_dtype, const float* rope_cos, const float* rope_sin,
+                              float* workspace, long workspace_bytes, int qsplit, int dq_mode, bool qs, hipStream_t stream);
 extern "C" int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
                                   const float* lse2, const float* delta, void* dq, long lddq, void* dk, void* dv, long lddk, int B, int H,
                                   int N, int head_dim, float scale, int out_dtype, const float* rope_cos, const float* rope_sin,
                                   float* workspace, long workspace_bytes, int qsplit, int dq_mode, hipStream_t stream) {
+  return mqa_bwd_fused_impl(q, ldq, k, ldk, v, ldv, dout, lddo, lse2, delta, dq, lddq, dk, dv, lddk, B, H, N, head_dim, scale, out_dtype, rope_cos,
+                            rope_sin, workspace, workspace_bytes, qsplit, dq_mode, false, stream);
+}
+// q pre-scaled by c = scale * log2 e (osuf_rope_cast_qs; lse2 from osuf_mqa_fwd_qs): p = exp2(Qs K^T - lse2) with no multiply; dq = scale dS K
+// as before (the gradient of the UN-scaled rotated q), dk = (scale / c) dS^T Qs.  The generated 512-key loop drops its 64 v_mul per pair.
+extern "C" int osuf_mqa_bwd_fused_qs(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
+                                     const float* lse2, const float* delta, void* dq, long lddq, void* dk, void* dv, long lddk, int B, int H,
+                                     int N, int head_dim, float scale, int out_dtype, const float* rope_cos, const float* rope_sin,
+                                     float* workspace, long workspace_bytes, int qsplit, int dq_mode, hipStream_t stream) {
+  return mqa_bwd_fused_impl(q, ldq, k, ldk, v, ldv, dout, lddo, lse2, delta, dq, lddq, dk, dv, lddk, B, H, N, head_dim, scale, out_dtype, rope_cos,
+                            rope_sin, workspace, workspace_bytes, qsplit, dq_mode, true, stream);
+}
+static int mqa_bwd_fused_impl(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* dout, long lddo,
+                              const float* lse2, const float* delta, void* dq, long lddq, void* dk, void* dv, long lddk, int B, int H,
+                              int N, int head_dim, float scale, int out_dtype, const float* rope_cos, const float* rope_sin,
+                              float* workspace, long workspace_bytes, int qsplit, int dq_mode, bool qs, hipStream_t stream) {
   AttnArgs a;
   int rc = fill_bwd_args(a, q, ldq, k, ldk, v, ldv, dout, lddo, lse2, delta, B, H, N, head_dim, scale);
   if (rc) return rc;
+  if (qs) { a.cexp = 1.f; a.kmul = 1.f / kLog2e; }
   if (lddq % 8 || lddk % 8 || !al16(dq) || !al16(dk) || !al16(dv) || (out_dtype != OSUF_DT_F32 && out_dtype != OSUF_DT_BF16) ||
       ((rope_cos == nullptr) != (rope_sin == nullptr)) || qsplit < 0 || qsplit > 16 || !workspace || !al16(workspace) ||
       !fused_mode_ok(dq_mode) || workspace_bytes < osuf_mqa_bwd_fused_workspace_bytes(B, H, N, out_dtype, qsplit, dq_mode))
@@ -2020,10 +2078,12 @@ extern "C" int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long l
     const int lds = 2 * (4096 + 4096 + 256) + 65536 + 2 * 32768;
     static bool attr512a = false;
     if (!attr512a) {
-      (void)hipFuncSetAttribute((const void*)mqa_bwd_fused512a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute((const void*)mqa_bwd_fused512a_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute((const void*)mqa_bwd_fused512a_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr512a = true;
     }
-    hipLaunchKernelGGL(mqa_bwd_fused512a_kernel, dim3((N / 512) * b8 * a.qsplit), dim3(256), lds, stream, a, dq32);
+    if (qs) hipLaunchKernelGGL(mqa_bwd_fused512a_kernel<true>, dim3((N / 512) * b8 * a.qsplit), dim3(256), lds, stream, a, dq32);
+    else hipLaunchKernelGGL(mqa_bwd_fused512a_kernel<false>, dim3((N / 512) * b8 * a.qsplit), dim3(256), lds, stream, a, dq32);
   } else if (use512) {
     const int lds = 2 * (4096 + 4096 + 256) + 65536 + 2 * 32768;
     void (*kern)(AttnArgs, float*) = dq_mode == OSUF_DQ_TIMING_512 ? mqa_bwd_fused512_kernel<false> : mqa_bwd_fused512_kernel<true>;
@@ -2050,8 +2110,8 @@ extern "C" int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long l
   }
   if (a.qsplit > 1) {
     const unsigned fb = (unsigned)((M * 32 + 255) / 256);
-    if (a.g_bf16) hipLaunchKernelGGL(dkv_finish_kernel<bf16_t>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (bf16_t*)dk, (bf16_t*)dv, lddk, M, N, scale, rope_cos, rope_sin);
-    else hipLaunchKernelGGL(dkv_finish_kernel<float>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (float*)dk, (float*)dv, lddk, M, N, scale, rope_cos, rope_sin);
+    if (a.g_bf16) hipLaunchKernelGGL(dkv_finish_kernel<bf16_t>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (bf16_t*)dk, (bf16_t*)dv, lddk, M, N, a.kmul, rope_cos, rope_sin);
+    else hipLaunchKernelGGL(dkv_finish_kernel<float>, dim3(fb), dim3(256), 0, stream, a.wsk, a.wsv, a.qsplit, (float*)dk, (float*)dv, lddk, M, N, a.kmul, rope_cos, rope_sin);
   }
   const int qb = ew_grid(M * H * 8);
   const int nkb = (N + 255) / 256, npad = (N + 31) / 32 * 32;
@@ -2066,8 +2126,20 @@ extern "C" int osuf_mqa_bwd_fused(const void* q, long ldq, const void* k, long l
   return osuf_launch_status();
 }
 
+static int rope_cast_impl(int dtype, const void* in, long ld_in, void* out, long ld_out, const float* cosb, const float* sinb,
+                          int M, int N, int n_rot_heads, int n_heads_total, int head_dim, float qmul, int n_q_heads, hipStream_t stream);
 extern "C" int osuf_rope_cast(int dtype, const void* in, long ld_in, void* out, long ld_out, const float* cosb, const float* sinb,
                               int M, int N, int n_rot_heads, int n_heads_total, int head_dim, hipStream_t stream) {
+  return rope_cast_impl(dtype, in, ld_in, out, ld_out, cosb, sinb, M, N, n_rot_heads, n_heads_total, head_dim, 1.f, 0, stream);
+}
+// as osuf_rope_cast, and the first n_q_heads heads (the queries) are multiplied by q_mul before their bf16 rounding (head_dim 64 only)
+extern "C" int osuf_rope_cast_qs(int dtype, const void* in, long ld_in, void* out, long ld_out, const float* cosb, const float* sinb,
+                                 int M, int N, int n_rot_heads, int n_heads_total, int head_dim, float q_mul, int n_q_heads, hipStream_t stream) {
+  if (head_dim != D || n_q_heads < 0 || n_q_heads > n_heads_total) return OSUF_EUNSUPPORTED;
+  return rope_cast_impl(dtype, in, ld_in, out, ld_out, cosb, sinb, M, N, n_rot_heads, n_heads_total, head_dim, q_mul, n_q_heads, stream);
+}
+static int rope_cast_impl(int dtype, const void* in, long ld_in, void* out, long ld_out, const float* cosb, const float* sinb,
+                          int M, int N, int n_rot_heads, int n_heads_total, int head_dim, float qmul, int n_q_heads, hipStream_t stream) {
   if (head_dim != D && (head_dim <= 0 || head_dim % 16)) return OSUF_EUNSUPPORTED;
   if (M <= 0 || N <= 0 || M % N || ld_in % 8 || ld_out % 8 || !al16(in) || !al16(out)) return OSUF_EINVAL;
   if (head_dim != D) {                                            // any head dim that is a multiple of 16: tables [N][head_dim / 2]
@@ -2079,9 +2151,9 @@ extern "C" int osuf_rope_cast(int dtype, const void* in, long ld_in, void* out, 
   }
   const long tot = (long)M * n_heads_total * 4;
   if (dtype == OSUF_DT_BF16) {
-    hipLaunchKernelGGL(rope_cast_kernel<bf16_t>, dim3(ew_grid(tot)), dim3(256), 0, stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, cosb, sinb, M, N, n_rot_heads, n_heads_total);
+    hipLaunchKernelGGL(rope_cast_kernel<bf16_t>, dim3(ew_grid(tot)), dim3(256), 0, stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, cosb, sinb, M, N, n_rot_heads, n_heads_total, qmul, n_q_heads);
   } else if (dtype == OSUF_DT_F32) {
-    hipLaunchKernelGGL(rope_cast_kernel<float>, dim3(ew_grid(tot)), dim3(256), 0, stream, (const float*)in, ld_in, (bf16_t*)out, ld_out, cosb, sinb, M, N, n_rot_heads, n_heads_total);
+    hipLaunchKernelGGL(rope_cast_kernel<float>, dim3(ew_grid(tot)), dim3(256), 0, stream, (const float*)in, ld_in, (bf16_t*)out, ld_out, cosb, sinb, M, N, n_rot_heads, n_heads_total, qmul, n_q_heads);
   } else return OSUF_EUNSUPPORTED;
   return osuf_launch_status();
 }

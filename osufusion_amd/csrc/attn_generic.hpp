@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void mqa_gen_fwd_kernel(AttnArgs a, int hd) {
   const int h = active ? vb % a.H : 0, pb = active ? vb / a.H : 0;
   const int qrow = pb * 32 + lr;
   const bool qok = active && qrow < a.N;
-  const float c = a.scale * kLog2e;
+  const float c = a.cexp;
   bf16x8 qf[T::KS];
   gen_load_row_frags<DP>(qf, a.q + ((long)b * a.N + qrow) * a.ldq + h * hd, qok, hd, lh);
   f32x16 o[T::DT];
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void mqa_gen_bwd_dq_kernel(AttnArgs a, int hd)
   const int h = active ? vb % a.H : 0, pb = active ? vb / a.H : 0;
   const int qrow = pb * 32 + lr;
   const bool qok = active && qrow < a.N;
-  const float c = a.scale * kLog2e;
+  const float c = a.cexp;
   bf16x8 qf[T::KS], dof[T::KS];
   gen_load_row_frags<DP>(qf, a.q + ((long)b * a.N + qrow) * a.ldq + h * hd, qok, hd, lh);
   gen_load_row_frags<DP>(dof, a.dout + ((long)b * a.N + qrow) * a.lddo + h * hd, qok, hd, lh);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void mqa_gen_bwd_dkv_kernel(AttnArgs a, int hd
   const int b = blockIdx.x / nkb, kb = blockIdx.x - b * nkb;
   const int key = kb * 128 + wave * 32 + lr;
   const bool kok = key < a.N;
-  const float c = a.scale * kLog2e;
+  const float c = a.cexp;
   const int nqb = (a.N + 31) >> 5;
   bf16x8 kf[T::KS], vf[T::KS];
   gen_load_row_frags<DP>(kf, a.k + ((long)b * a.N + key) * a.ldk, kok, hd, lh);

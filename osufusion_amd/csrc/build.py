@@ -15,7 +15,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 LIB = HERE / "libosuf_hip.so"
 
 
-ATTN_SOURCES = ["attn.hip", "attn_bwd512_asm.inc", "attn_generic.hpp", "common.hpp"]
+ATTN_SOURCES = ["attn.hip", "attn_bwd512_asm.inc", "attn_bwd512qs_asm.inc", "attn_generic.hpp", "common.hpp"]
 
 
 def source_hash(names=ATTN_SOURCES) -> str:
@@ -32,7 +32,7 @@ def _stale() -> bool:
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    deps = [HERE / s for s in SOURCES] + [HERE / "common.hpp", HERE / "attn_generic.hpp", HERE / "attn_bwd512_asm.inc", Path(__file__)]
+    deps = [HERE / s for s in SOURCES] + [HERE / "common.hpp", HERE / "attn_generic.hpp", HERE / "attn_bwd512_asm.inc", HERE / "attn_bwd512qs_asm.inc", Path(__file__)]
     return any(d.stat().st_mtime > t for d in deps)
 
 

@@ -902,10 +902,13 @@ class AttentionFn(torch.autograd.Function):
         wqkv = AttentionFn._qkv_packs(cache, dt, wq, wkv, aq, akv, base)[0]
         qkv = ops.gemm_nt(xn, wqkv, None, out_shape=(B, N, (H + 2 * G) * D))
         cos, sin = rope_tables(N, D, scale_base, x.device)
-        qkv_r = ops.rope_cast(qkv, cos, sin, N, H + G, H + 2 * G, D)            # rotate q heads and k heads; cast v
-        del qkv
         scale = D ** -0.5
-        o, lse = ops.mqa_fwd(qkv_r, B, N, H, D, dt, scale, kv_heads=G)
+        # the softmax scale (x log2 e) rides the queries' one bf16 rounding where the kernels have the pre-scaled form: the attention backward's
+        # generated loop then takes Qs K^T - lse2 straight as the exponent (64 fewer vector instructions per (head, query block) pair)
+        qs = ops.q_prescale_ok(D, ops.ATTN_BWD_DEFAULT)
+        qkv_r = ops.rope_cast(qkv, cos, sin, N, H + G, H + 2 * G, D, q_mul=scale * ops.LOG2E if qs else 1.0, n_q_heads=H)   # rotate q and k heads; cast v
+        del qkv
+        o, lse = ops.mqa_fwd(qkv_r, B, N, H, D, dt, scale, kv_heads=G, qs=qs)
         wpo = cache.packs(("po", dt), (wo,) if base is None else (base[1],), wo, "same", dt)[0]
         out = ops.gemm_nt(o, wpo, bo, residual=xn, out_shape=x.shape)
         ctx.base = base
@@ -913,6 +916,7 @@ class AttentionFn(torch.autograd.Function):
         ctx.cache, ctx.geom = cache, (H, D, scale_base, scale, G)
         ctx.nb, ctx.bo = nb, bo
         ctx.aq, ctx.akv = aq, akv
+        ctx.qs = qs
         return out
 
     @staticmethod
@@ -948,8 +952,11 @@ class AttentionFn(torch.autograd.Function):
         do16 = ops.cast_rows(do, torch.bfloat16)                                 # SDPA backward runs in bf16 (attention.py:101)
         # attention + rope
         cos, sin = rope_tables(N, D, scale_base, x.device)
-        dqkv = ops.mqa_bwd(qkv_r, o, do16, lse, B, N, H, D, scale, dt, cos, sin, variant=ops.ATTN_BWD_DEFAULT, delta=delta,
-                           kv_heads=G)                                           # RoPE transpose + cast ride the kernels' epilogues
+        variant = ops.ATTN_BWD_DEFAULT
+        if ctx.qs and variant not in ops._FUSED_DQ_MODE:                         # the default changed between forward and backward (tests do): the
+            variant = ops.ATTN_FUSED                                             # saved queries are pre-scaled, only the fused sweeps read those
+        dqkv = ops.mqa_bwd(qkv_r, o, do16, lse, B, N, H, D, scale, dt, cos, sin, variant=variant, delta=delta,
+                           kv_heads=G, qs=ctx.qs)                                # RoPE transpose + cast ride the kernels' epilogues
         # to_q / to_kv
         dwq = conv_wgrad(dqkv[..., : H * D], xn, wq, "same") if need[3] else None
         dwkv = conv_wgrad(dqkv[..., H * D:], xn, wkv, "same") if need[4] else None

@@ -166,14 +166,18 @@ def zeros(shape, dtype: torch.dtype, device) -> torch.Tensor:
     return torch.zeros(shape, dtype=dtype, device=device)
 
 
+_TIMED_AS = {"osuf_mqa_fwd_qs": "osuf_mqa_fwd", "osuf_mqa_bwd_fused_qs": "osuf_mqa_bwd_fused"}    # pre-scaled-query forms: timed under the plain name
+
+
 def call(name: str, *args, meta=None) -> None:
     lib = _lib.load()
-    if _TIMER is not None and name in _TIMER.names:
+    tname = _TIMED_AS.get(name, name)
+    if _TIMER is not None and tname in _TIMER.names:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         _lib.check(getattr(lib, name)(*args), name)
         e.record()
-        _TIMER.records[name].append((s, e, meta))
+        _TIMER.records[tname].append((s, e, meta))
         return
     _lib.check(getattr(lib, name)(*args), name)
 
@@ -407,10 +411,26 @@ def gca_bwd_apply(dout, h, p, gate, dpooled, sdot, wk, L: int, dwk_out: Optional
 # ---------------------------------------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------------------------------------
-def rope_cast(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, N: int, n_rot: int, n_heads: int, head_dim: int) -> torch.Tensor:
+LOG2E = 1.4426950408889634
+
+
+def q_prescale_ok(head_dim: int, variant: int) -> bool:
+    """May AttentionFn fold the softmax scale into the queries' bf16 rounding (osuf_rope_cast_qs -> osuf_mqa_fwd_qs -> osuf_mqa_bwd_fused_qs)?
+    Only the 64-wide kernels and the fused backward sweeps have the pre-scaled form; OSUF_ATTN_NO_QS=1 switches it off (A/B runs)."""
+    import os
+    return head_dim == 64 and variant in _FUSED_DQ_MODE and not os.environ.get("OSUF_ATTN_NO_QS")
+
+
+def rope_cast(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, N: int, n_rot: int, n_heads: int, head_dim: int,
+              q_mul: float = 1.0, n_q_heads: int = 0) -> torch.Tensor:
+    """RoPE + bf16 cast of q | k | v rows.  q_mul != 1: the first n_q_heads heads (the queries) are multiplied by q_mul = scale * log2 e
+    before their one bf16 rounding -- the attention kernels' *_qs forms then take the scores straight as exponents."""
     M, W, ld = _rows(qkv)
     out = torch.empty(qkv.shape, dtype=torch.bfloat16, device=qkv.device)
-    call("osuf_rope_cast", dt_of(qkv), _p(qkv), ld, _p(out), W, _p(cos), _p(sin), M, N, n_rot, n_heads, head_dim, _stream())
+    if q_mul != 1.0:
+        call("osuf_rope_cast_qs", dt_of(qkv), _p(qkv), ld, _p(out), W, _p(cos), _p(sin), M, N, n_rot, n_heads, head_dim, q_mul, n_q_heads, _stream())
+    else:
+        call("osuf_rope_cast", dt_of(qkv), _p(qkv), ld, _p(out), W, _p(cos), _p(sin), M, N, n_rot, n_heads, head_dim, _stream())
     return out
 
 
@@ -421,10 +441,11 @@ def rope_bwd(dqkv32: torch.Tensor, out_dtype: torch.dtype, cos, sin, N: int, n_r
     return out
 
 
-def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.dtype, scale: float, kv_heads: int = 1):
+def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.dtype, scale: float, kv_heads: int = 1, qs: bool = False):
     """qkv: bf16 rows [B*N][(H+2G)*D] (q heads | G k heads | G v heads).  Returns o rows [B*N][H*D] and lse2 [B][H][N].
     G = kv_heads > 1 (grouped-query attention, unet.py:135): the q heads are laid out GROUP-MAJOR -- heads g*H/G .. (g+1)*H/G - 1
-    share K/V head g -- and every group is one launch of the one-K/V-head kernels on its column block; lse2 is then [G][B][H/G][N]."""
+    share K/V head g -- and every group is one launch of the one-K/V-head kernels on its column block; lse2 is then [G][B][H/G][N].
+    qs: the q columns hold queries pre-scaled by scale * log2 e (rope_cast(q_mul=...))."""
     M, W, ld = _rows(qkv)
     G = kv_heads
     assert qkv.dtype == torch.bfloat16 and W == (H + 2 * G) * D and H % G == 0
@@ -433,7 +454,7 @@ def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.
     lse = torch.empty((B, H, N) if G == 1 else (G, B, r, N), dtype=torch.float32, device=qkv.device)
     base, eo = qkv.data_ptr(), o.element_size()
     for g in range(G):
-        call("osuf_mqa_fwd", base + 2 * g * r * D, ld, base + 2 * (H + g) * D, ld, base + 2 * (H + G + g) * D, ld, o.data_ptr() + eo * g * r * D,
+        call("osuf_mqa_fwd_qs" if qs else "osuf_mqa_fwd", base + 2 * g * r * D, ld, base + 2 * (H + g) * D, ld, base + 2 * (H + G + g) * D, ld, o.data_ptr() + eo * g * r * D,
              H * D, _DT[out_dtype], lse.data_ptr() + 4 * g * B * r * N, B, r, N, D, scale, _stream(), meta=LaunchSize(N, B))
     return o, lse
 
@@ -464,7 +485,7 @@ FUSE_ROWDOT = True      # AttentionFn.backward: sum_d dO * O from the to_out dgr
 
 def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, D: int, scale: float,
             out_dtype: torch.dtype = torch.float32, cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None,
-            variant: int = ATTN_AUTO, qsplit: int = 0, delta: Optional[torch.Tensor] = None, kv_heads: int = 1) -> torch.Tensor:
+            variant: int = ATTN_AUTO, qsplit: int = 0, delta: Optional[torch.Tensor] = None, kv_heads: int = 1, qs: bool = False) -> torch.Tensor:
     """Gradients laid out like qkv, [B*N][(H+2G)*D], in out_dtype.  With the RoPE tables (N, D/2) the q / k gradients are those of
     the un-rotated projections (the rotation's transpose is applied in the kernels' epilogues).  kv_heads = G > 1: one launch set
     per group on its column blocks (see mqa_fwd; lse / delta are [G][B][H/G][N])."""
@@ -494,9 +515,10 @@ def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Ten
             mode = _FUSED_DQ_MODE[variant]
             need = _lib.load().osuf_mqa_bwd_fused_workspace_bytes(B, r, N, _DT[out_dtype], qsplit, mode)
             ws = _workspace(need, qkv.device)
-            call("osuf_mqa_bwd_fused", q_, ld, k_, ld, v_, ld, do_, ldo_, lse_, delta_, dq_, W, dk_, dv_, W, B, r, N, D, scale, _DT[out_dtype],
+            call("osuf_mqa_bwd_fused_qs" if qs else "osuf_mqa_bwd_fused", q_, ld, k_, ld, v_, ld, do_, ldo_, lse_, delta_, dq_, W, dk_, dv_, W, B, r, N, D, scale, _DT[out_dtype],
                  _p(cos), _p(sin), _p(ws), need, qsplit, mode, _stream(), meta=N)
             continue
+        assert not qs, "pre-scaled queries: only the fused sweeps have that form"
         call("osuf_mqa_bwd_dq", q_, ld, k_, ld, v_, ld, do_, ldo_, lse_, delta_, dq_, W, B, r, N, D, scale, _DT[out_dtype],
              _p(cos), _p(sin), variant, _stream(), meta=N)
         need = _lib.load().osuf_mqa_bwd_dkv_workspace_bytes(B, N, qsplit)  # > 0: short sequence (or forced), the query range is split

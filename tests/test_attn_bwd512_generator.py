@@ -17,6 +17,18 @@ def test_committed_loop_is_the_generators_output(tmp_path):
     assert "non-MFMA instructions per pair" in r.stdout
 
 
+def test_committed_prescaled_query_loop_is_the_generators_output(tmp_path):
+    """--qs: the variant for queries pre-scaled by scale * log2 e (osuf_mqa_bwd_fused_qs): same generator, same checks, 64 fewer vector
+    instructions per pair, its own committed text"""
+    out = tmp_path / "loop_qs.inc"
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_attn_bwd512.py"), "--qs", "--stats", "--out", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out.read_text() == (ROOT / "osufusion_amd" / "csrc" / "attn_bwd512qs_asm.inc").read_text()
+    n = int(r.stdout.split("non-MFMA instructions per pair: ")[1].split(";")[0])
+    assert n <= 440, n
+    assert "v_mul_f32_e32 v128, s74" not in out.read_text()          # no score multiply left
+
+
 def test_hand_ordered_body_still_generates(tmp_path):
     """--manual: the body the list-scheduled one is compared against (pinned on the GPU: dK / dV bit-identical to the compiled sweep)"""
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_attn_bwd512.py"), "--manual", "--out", str(tmp_path / "m.inc")], capture_output=True, text=True)
@@ -27,6 +39,7 @@ def test_loop_text_has_no_mfma_hazard_and_stays_on_its_diet():
     sys.path.insert(0, str(ROOT / "tools"))
     import check_mfma_hazards as H
     assert H.check_inc(str(ROOT / "osufusion_amd" / "csrc" / "attn_bwd512_asm.inc"), max_non_mfma=600)
+    assert H.check_inc(str(ROOT / "osufusion_amd" / "csrc" / "attn_bwd512qs_asm.inc"), max_non_mfma=600)
 
 
 def test_a_broken_schedule_is_caught(tmp_path):
@@ -51,6 +64,12 @@ def test_every_global_address_of_the_loop_is_the_element_it_should_be():
     lines, clob = C.inc_lines(C.INC)
     errs, checked = C.check_text(lines, clob, quick=True, verbose=False)
     assert errs == 0 and checked > 100_000
+    # the pre-scaled-query variant forms the same addresses: two short shape families + its clobber list
+    qlines, qclob = C.inc_lines(C.INC.with_name("attn_bwd512qs_asm.inc"))
+    assert not C.check_clobbers(qlines, qclob)
+    for shp in ((2, 1024, 1, 2), (2, 1024, 16, 2), (1, 512, 2, 16)):
+        sh = C.Shape(*shp, b=shp[0] - 1, part=shp[3] - 1)
+        assert sum(len(C.run(qlines, sh, w)[0]) for w in range(4)) == 0
 
     def findings(mutate):
         bad = mutate(list(lines))

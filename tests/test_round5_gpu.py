@@ -125,3 +125,56 @@ def test_generated_attention_backward_one_head_paths(Bn, N, H, G, qsplit):
     e = ((got - g_ref).norm() / g_ref.norm()).item()
     report(f"attn_bwd512a_one_head/B{Bn}_N{N}_H{H}_G{G}_qs{qsplit}", dq_vs_compiled=e_dq, vs_autograd=e)
     assert e_dq < 1e-5 and e < 1e-2
+
+
+@pytest.mark.parametrize("Bn,N,H,G", [(2, 512, 4, 1), (1, 2048, 16, 1), (2, 1024, 4, 2), (2, 1024, 1, 1), (2, 200, 2, 1)])
+def test_attention_with_prescaled_queries(Bn, N, H, G):
+    """The softmax scale folded into the queries' bf16 rounding (osuf_rope_cast_qs -> osuf_mqa_fwd_qs -> osuf_mqa_bwd_fused_qs; attention.py:87-99
+    rounds q to bf16 and scales the scores, here q * scale * log2 e is rounded once and the scores ARE the exponents): forward and every gradient
+    (of the un-rotated, un-scaled projections) against autograd of the fp32 formula on the SAME pre-RoPE inputs, next to the unscaled path; the
+    generated 512-key loop's pre-scaled variant bit-identical (dK / dV) to the compiled sweep fed the same pre-scaled queries."""
+    D = 64
+    r = H // G
+    scale = D ** -0.5
+    raw = torch.randn(Bn, N, (H + 2 * G) * D, device=DEV).to(torch.bfloat16)          # projections before RoPE
+    do = torch.randn(Bn, N, H * D, device=DEV).to(torch.bfloat16)
+    cos, sin = Fn.rope_tables(N, D, 2 * N, DEV)
+    # fp32 reference: RoPE (half-split), per-group attention, autograd
+    x = raw.float().cpu().requires_grad_()
+    c_, s_ = cos.cpu(), sin.cpu()
+
+    def rot(t):                                                                       # (Bn, N, heads, D)
+        t1, t2 = t[..., :32], t[..., 32:]
+        return torch.cat([t1 * c_[None, :, None] - t2 * s_[None, :, None], t2 * c_[None, :, None] + t1 * s_[None, :, None]], -1)
+    q = rot(x[..., : H * D].view(Bn, N, H, D))
+    k = rot(x[..., H * D:(H + G) * D].view(Bn, N, G, D))
+    v = x[..., (H + G) * D:].view(Bn, N, G, D)
+    outs = []
+    for g in range(G):
+        sc = torch.einsum("bnhd,bmd->bhnm", q[:, :, g * r:(g + 1) * r], k[:, :, g]) * scale
+        outs.append(torch.einsum("bhnm,bmd->bnhd", sc.softmax(-1), v[:, :, g]).reshape(Bn, N, r * D))
+    o_ref = torch.cat(outs, -1)
+    o_ref.backward(do.float().cpu())
+    g_ref = x.grad.to(DEV)
+    res = {}
+    for name, qs in (("plain", False), ("qs", True)):
+        qkv_r = ops.rope_cast(raw, cos, sin, N, H + G, H + 2 * G, D, q_mul=scale * ops.LOG2E if qs else 1.0, n_q_heads=H)
+        o, lse = ops.mqa_fwd(qkv_r, Bn, N, H, D, torch.bfloat16, scale, kv_heads=G, qs=qs)
+        dqkv = ops.mqa_bwd(qkv_r, o, do, lse, Bn, N, H, D, scale, torch.float32, cos, sin, variant=ops.ATTN_FUSED, kv_heads=G, qs=qs)
+        res[name] = (o.float(), lse, dqkv)
+        e_o = ((o.float().cpu() - o_ref.detach()).norm() / o_ref.detach().norm()).item()
+        e_g = ((dqkv - g_ref).norm() / g_ref.norm()).item()
+        parts = {nm: ((dqkv[..., sl] - g_ref[..., sl]).norm() / g_ref[..., sl].norm()).item()
+                 for nm, sl in (("dq", slice(0, H * D)), ("dk", slice(H * D, (H + G) * D)), ("dv", slice((H + G) * D, None)))}
+        report(f"attn_prescaled_q/B{Bn}_N{N}_H{H}_G{G}/{name}", out=e_o, grad=e_g, **parts)
+        assert e_o < 5e-3 and e_g < 1e-2 and max(parts.values()) < 1e-2, (name, e_o, e_g, parts)
+    # the two roundings of q differ by bf16 noise, no more; the log2-domain lse agrees to fp32 noise of the scores
+    assert ((res["qs"][0] - res["plain"][0]).norm() / res["plain"][0].norm()).item() < 5e-3
+    assert (res["qs"][1] - res["plain"][1]).abs().max().item() < 5e-2
+    if N % 512 == 0:
+        qkv_r = ops.rope_cast(raw, cos, sin, N, H + G, H + 2 * G, D, q_mul=scale * ops.LOG2E, n_q_heads=H)
+        o, lse = ops.mqa_fwd(qkv_r, Bn, N, H, D, torch.bfloat16, scale, kv_heads=G, qs=True)
+        a = ops.mqa_bwd(qkv_r, o, do, lse, Bn, N, H, D, scale, torch.float32, cos, sin, variant=ops.ATTN_FUSED512A, kv_heads=G, qs=True)
+        b = ops.mqa_bwd(qkv_r, o, do, lse, Bn, N, H, D, scale, torch.float32, cos, sin, variant=ops.ATTN_FUSED512, kv_heads=G, qs=True)
+        assert torch.equal(a[..., H * D:], b[..., H * D:])
+        assert ((a[..., : H * D] - b[..., : H * D]).norm() / b[..., : H * D].norm()).item() < 1e-5

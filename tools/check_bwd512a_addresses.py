@@ -11,7 +11,8 @@ prologue of the kernel hands to the asm statement, restated here from csrc/attn.
   * the LDS destination of every LDS-DMA (m0) is one of the two stage slots;
   * every register the text writes that is not a '+' / '=' operand of the asm statement is in its clobber list (m0).
 Shapes: every (N, H, qsplit, row strides) family the launcher admits, including H == 1, the minimum trip count and strides near the 32-bit
-guard of fused512a_ok().       python tools/check_bwd512a_addresses.py [file.inc]"""
+guard of fused512a_ok().       python tools/check_bwd512a_addresses.py [--quick] [file.inc]   (default: attn_bwd512_asm.inc; the pre-scaled-query
+variant attn_bwd512qs_asm.inc forms the same addresses and is checked the same way)"""
 from __future__ import annotations
 
 import re
@@ -33,7 +34,7 @@ def inc_lines(path):
         m = re.match(r'\s*"(.*)\\n\\t" \\$', l)
         if m:
             out.append(m.group(1))
-        if l.startswith("#define OSUF_BWD512A_CLOBBERS"):
+        if re.match(r"#define OSUF_BWD512A(QS)?_CLOBBERS", l):
             clob = set(re.findall(r'"([^"]+)"', l))
     return out, clob
 

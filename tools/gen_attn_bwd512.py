@@ -30,7 +30,11 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-OUT = ROOT / "osufusion_amd" / "csrc" / "attn_bwd512_asm.inc"
+# --qs: the variant for queries that arrive PRE-SCALED by c = scale log2 e (osuf_rope_cast_qs folds the softmax scale into the bf16 rounding of
+# the rotated q): S' = Qs K^T - lse2 leaves the MFMA chain already in the log2 domain, so the 64 `v_mul_f32 S, c, S` of a pair are not emitted
+# (the row constant is -lse2: the C++ side passes -1 for -1/c).  Second output file / macro pair, same register map.
+QS = "--qs" in sys.argv
+OUT = ROOT / "osufusion_amd" / "csrc" / ("attn_bwd512qs_asm.inc" if QS else "attn_bwd512_asm.inc")
 # timing-only triage builds (wrong results, never shipped): --drop valu,atomics,dq,lds,barrier,dma  --out <file>
 DROP = set()
 for i, a in enumerate(sys.argv):
@@ -293,6 +297,8 @@ SC2 = 92                                                         # s[92:93] = (c
 
 
 def mul_exp(e, r):
+    if QS:                                                       # pre-scaled queries: the chain's result is the exponent itself
+        return
     if PKC:
         if r % 2 == 0:
             e.valu(f"v_pk_mul_f32 {vr(S + r, 2)}, {vr(S + r, 2)}, s[{SC2}:{SC2 + 1}]", vset(S + r, 2), vset(S + r, 2))
@@ -656,7 +662,7 @@ def body_sched(e, sg, tag):
         vdead = lambda r: idx[f"V{t}.0"] if r < 8 else idx[f"V{t}.2"]
         snext = idx[f"S{t + 1}.0"] if t < 3 else 10 ** 6          # readers of S sit before the next tile's S chain
         for jj in range(8):
-            add(f"mm{t}.{jj}", (lambda jj=jj: (mul_exp(e, 2 * jj), mul_exp(e, 2 * jj + 1))), 2 * C_V, "V", after=s_done, before=vdead(2 * jj))
+            add(f"mm{t}.{jj}", (lambda jj=jj: (mul_exp(e, 2 * jj), mul_exp(e, 2 * jj + 1))), 0 if QS else 2 * C_V, "V", after=s_done, before=vdead(2 * jj))
             add(f"ee{t}.{jj}", (lambda jj=jj: (exp(e, 2 * jj), exp(e, 2 * jj + 1))), 2 * C_EXP, "V", deps=(f"mm{t}.{jj}",), before=vdead(2 * jj))
         for q in range(4):
             add(f"pf{t}.{q}", (lambda q=q: (cvt(e, PF + 2 * q, S + 4 * q), cvt(e, PF + 2 * q + 1, S + 4 * q + 2))), 2 * C_V, "V",
@@ -851,15 +857,16 @@ def main():
     e, loop_len, loop_count, chk = generate()
     text = e.lines
     with open(OUT, "w") as f:
-        f.write("// GENERATED by tools/gen_attn_bwd512.py -- do not edit.  Main loop of mqa_bwd_fused512a_kernel (csrc/attn.hip) as one asm statement.\n")
+        macro = "OSUF_BWD512AQS" if QS else "OSUF_BWD512A"
+        f.write(f"// GENERATED by tools/gen_attn_bwd512.py{' --qs' if QS else ''} -- do not edit.  Main loop of mqa_bwd_fused512a_kernel (csrc/attn.hip) as one asm statement.\n")
         f.write("// register map: see the generator; the C++ side binds its operands to the same physical registers.\n")
-        f.write("#define OSUF_BWD512A_ASM \\\n")
+        f.write(f"#define {macro}_ASM \\\n")
         for l in text:
             f.write(f'  "{l}\\n\\t" \\\n')
         f.write('  ""\n')
         cl = ", ".join(f'"v{i}"' for i in range(64, 192)) + ", " + ", ".join(f'"a{i}"' for i in range(256))
         sc = ", ".join(f'"s{i}"' for i in (SD128, SDN4, SDQS, SHS, SHD, SMASK, SMASK + 1) + tuple(range(SROW, SROW + 8)) + (SC2, SC2 + 1))
-        f.write(f'#define OSUF_BWD512A_CLOBBERS "memory", "vcc", "scc", "m0", {sc}, {cl}\n')     # m0: the LDS-DMA destinations
+        f.write(f'#define {macro}_CLOBBERS "memory", "vcc", "scc", "m0", {sc}, {cl}\n')     # m0: the LDS-DMA destinations
     if "--stats" in sys.argv:
         per_pair = {k: v / 2 for k, v in loop_count.items() if k not in ("init", "fini")}
         tot = sum(v for k, v in per_pair.items() if not k.startswith("mfma"))
