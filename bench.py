@@ -186,7 +186,8 @@ def sampler_secondary(model, device):
         pmc, (man, why) = {}, pmc_manifest()
         if man is not None:
             try:
-                pmc = json.loads((ROOT / man["sampler"]).read_text())["kernels"].get("mqa_fwd_kernel<8>", {})
+                kern = json.loads((ROOT / man["sampler"]).read_text())["kernels"]
+                pmc = next((v for k, v in kern.items() if k.startswith("mqa_fwd_kernel<8")), {})      # <8> or <8, true> (pre-scaled queries)
                 why = f"{man['sampler']} [tree {man.get('tree')}] (rocprofv3 --pmc passes over tools/sampler_short.py, S = 3)"
             except (OSError, ValueError, KeyError):
                 why = f"{man['sampler']} unreadable"

@@ -161,7 +161,9 @@ struct KVStage {
 // (A two-wave-group variant skewed by half a tile with LDS-DMA staging was measured at 590-605 TFLOP/s against 803 for
 //  this single-phase loop -- two barriers per tile and the serial MFMA -> max -> exp chain cost more than the overlap won.)
 // ------------------------------------------------------------------------------------------------------
-template <int NW>
+// QS (queries pre-scaled by scale * log2 e, osuf_mqa_fwd_qs): the scores ARE the exponents, so the running maximum rides the S chain as its C
+// operand (S' = K Qs^T - m_run: 16 registers that change only when a row is rescaled) and p = exp2(S') needs no per-element fma
+template <int NW, bool QS = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][K 8K | V 8K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = QS ? 0.f : -INFINITY, l_run = 0.f;
 
   const LaneOffs lo(lane);
   const int ntiles = (a.N + 63) >> 6;
@@ -215,12 +217,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+    f32x16 negm;                                            // QS: -m_run in every register, the C operand of the S chain's first MFMA
+    if constexpr (QS) {
+      float nm = -m_run;
+      asm volatile("" : "+v"(nm));                          // rebuilt per tile -- 16 moves -- instead of 16 registers live across the loop: kept
+#pragma unroll                                              // live the kernel needs 128 VGPRs + 40 B of scratch (971 vs 993 TFLOP/s at N = 4096)
+      for (int r = 0; r < 16; ++r) negm[r] = nm;
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const bf16x8 qf = lds_row_frag(qtile, lo, ks, 0);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(ks_, lo, ks, kt), qf, s[kt], 0, 0, 0);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(ks_, lo, ks, kt), qf, (QS && ks == 0) ? negm : s[kt], 0, 0, 0);
     }
     if constexpr (MASK) {
 #pragma unroll
@@ -236,6 +245,35 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+    float ps0 = 0.f, ps1 = 0.f;
+    if constexpr (QS) {
+      // s holds S - m_run already.  Rescale (wave-uniform branch) when a row's maximum grew by more than 2^6 -- and on the first tile, which
+      // sets the running maximum exactly (its accumulators are still zero: no alpha there)
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (j == 0 || __any(mx > 6.0f)) {
+        const float d = j == 0 ? mx : fmaxf(mx, 0.f);
+        const float alpha = j == 0 ? 1.f : fast_exp2(-d);
+        m_run += d;
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kt][r] -= d;
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          float p0 = fast_exp2(s[kt][r]);
+          float p1 = fast_exp2(s[kt][r + 1]);
+          s[kt][r] = p0; s[kt][r + 1] = p1;
+          ps0 += p0; ps1 += p1;
+        }
+    } else {
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
     // lazy rescale: keep the running max while no row's max grew by more than 2^6 (P <= 64: bf16 rounding is scale-free);
     // the branch is wave-uniform
@@ -250,7 +288,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
     }
     // (the packed forms v_pk_fma_f32 / v_pk_add_f32 of these two elementwise streams were measured 4 % SLOWER: N = 8192 9.36 -> 9.75 ms)
-    float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -260,6 +297,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
         s[kt][r] = p0; s[kt][r + 1] = p1;
         ps0 += p0; ps1 += p1;
       }
+    }
     l_run += ps0 + ps1;
     // O^T += V^T P^T
 #pragma unroll
@@ -1830,7 +1868,8 @@ static int mqa_fwd_impl(const void* q, long ldq, const void* k, long ldk, const 
     else hipLaunchKernelGGL(mqa_gen_fwd_kernel<128>, grid, dim3(256), 2 * 64 * 256, stream, a, head_dim);
     return osuf_launch_status();
   }
-  hipLaunchKernelGGL(mqa_fwd_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768 + 8 * 4096, stream, a);
+  if (qs && getenv("OSUF_ATTN_FWD_NOQSK") == nullptr) hipLaunchKernelGGL((mqa_fwd_kernel<8, true>), dim3((nvb + 7) / 8, B), dim3(512), 32768 + 8 * 4096, stream, a);
+  else hipLaunchKernelGGL(mqa_fwd_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768 + 8 * 4096, stream, a);
   return osuf_launch_status();
 }
 
