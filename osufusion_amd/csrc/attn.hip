@@ -156,6 +156,49 @@ struct KVStage {
   }
 };
 
+// the same stage with RUNNING source pointers (forward kernel, round 5): the tile loop's loads are `pointer += 64 rows` instead of two 64-bit
+// multiply-adds per tile (the compiled loop spent ~21 vector instructions per tile, four of them quarter-rate v_mul_lo_u32, on these addresses)
+template <int NT>
+struct KVStageInc {
+  static constexpr int PER = 512 / NT;
+  u32x4 rk[PER], rv[PER];
+  const bf16_t* pk[PER];
+  const bf16_t* pv[PER];
+  int row[PER];
+  long stepk, stepv;
+  __device__ __forceinline__ void init(const AttnArgs& a, int b, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int cid = tid + i * NT, chunk = cid & 7;
+      row[i] = cid >> 3;
+      const long m = (long)b * a.N + row[i];
+      pk[i] = a.k + m * a.ldk + chunk * 8;
+      pv[i] = a.v + m * a.ldv + chunk * 8;
+    }
+    stepk = 64 * a.ldk; stepv = 64 * a.ldv;
+  }
+  __device__ __forceinline__ void load(const AttnArgs& a, int key0) {      // tiles in order: key0 = 0, 64, 128, ...
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      u32x4 z = {0u, 0u, 0u, 0u};
+      rk[i] = z; rv[i] = z;
+      if (key0 + row[i] < a.N) {
+        rk[i] = *reinterpret_cast<const u32x4*>(pk[i]);
+        rv[i] = *reinterpret_cast<const u32x4*>(pv[i]);
+      }
+      pk[i] += stepk; pv[i] += stepv;
+    }
+  }
+  __device__ __forceinline__ void store(char* ks, char* vs, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int cid = tid + i * NT, r = cid >> 3, chunk = cid & 7;
+      *reinterpret_cast<u32x4*>(ks + tile_off(r, chunk * 16)) = rk[i];
+      *reinterpret_cast<u32x4*>(vs + tile_off(r, chunk * 16)) = rv[i];
+    }
+  }
+};
+
 // ------------------------------------------------------------------------------------------------------
 // forward
 // (A two-wave-group variant skewed by half a tile with LDS-DMA staging was measured at 590-605 TFLOP/s against 803 for
@@ -199,8 +242,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
 
   const LaneOffs lo(lane);
   const int ntiles = (a.N + 63) >> 6;
-  KVStage<NW * 64> st;
-  st.load(a, b, 0, tid);
+  KVStageInc<NW * 64> st;
+  st.init(a, b, tid);
+  st.load(a, 0);
   st.store(smem, smem + 8192, tid);
   __syncthreads();
   // one 64-key tile; MASK only for a ragged last tile (a branch-free mask on every tile costs 64 VALU ops per tile)
@@ -209,7 +253,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
     const char* ks_ = smem + (j & 1) * 16384;
     const char* vs_ = ks_ + 8192;
 #ifndef OSUF_FWD_TRIAGE_NOLOAD
-    if (j + 1 < ntiles) st.load(a, b, (j + 1) * 64, tid);
+    if (j + 1 < ntiles) st.load(a, (j + 1) * 64);
 #endif
     // S^T = K Q^T  (two 32-key tiles)
     f32x16 s[2];
