@@ -289,6 +289,8 @@ def main() -> None:
                          "fused256 / fused512 = force that sweep (A/B); pair = dQ + dK/dV kernels; slabs = fused, fixed-order dQ")
     ap.add_argument("--timed-mode", choices=["bf16", "fp32x3", "fp32"], default="bf16",
                     help="profiling only: run the TIMED region in an fp32 compute mode (the headline metric is bf16; such a line is labelled)")
+    ap.add_argument("--grad-comm", choices=["fp32", "bf16"], default="fp32",
+                    help="N > 1: element type of the gradient all-reduce (bf16 halves the xGMI bytes at one bf16 rounding per rank contribution; default fp32)")
     ap.add_argument("--no-fuse-rowdot", action="store_true", help="A/B: sum(dO*O) by the stand-alone pass instead of the to_out dgrad epilogue")
     args = ap.parse_args()
 
@@ -324,7 +326,8 @@ def main() -> None:
         ops.ATTN_BWD_DEFAULT = {"fused": ops.ATTN_FUSED, "slabs": ops.ATTN_FUSED_SLABS, "pair": ops.ATTN_AUTO, "fused256": ops.ATTN_FUSED256,
                                 "fused512": ops.ATTN_FUSED512}[args.attn_bwd]
     trainer = Trainer(model, lr=1e-4, weight_decay=1e-2, clip_grad_norm=1.0,
-                      compute_dtype=torch.bfloat16 if args.timed_mode == "bf16" else torch.float32)
+                      compute_dtype=torch.bfloat16 if args.timed_mode == "bf16" else torch.float32,
+                      comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None)
     if args.timed_mode == "fp32x3":
         ops.set_f32_matmul("x3")
     x, a, c, noise, t = synth_batch(rank, device, args.batch, args.length)
