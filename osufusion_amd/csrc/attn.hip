@@ -1542,10 +1542,11 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512a_kernel(AttnArgs a, f
   const int kb = qid % nkb;
   if (b >= a.B) return;
   float c = a.cexp;
-  // c is pinned into a VECTOR register before the two v_readfirstlane statements below.  With the kernel argument left in its SGPR (hipcc then
-  // copies it by a v_mov right in front of the inline-asm v_readfirstlane) the non-QS loop ran with wrong row constants -- every gradient
-  // ~0.6 N times too large -- in two builds that differ in nothing but this line (tools/check_bwd512a.py; the printed c and -1/c were right,
-  // the emitted instruction streams equal up to register names: the mechanism was NOT identified; tests/test_asm_hazards.py refuses that shape)
+  // c is pinned into a VECTOR register, and the v_readfirstlane statements below carry their own s_nop pads: a vector write of the source
+  // register DIRECTLY in front of an inline-asm v_readfirstlane is a hazard hipcc pads for its own instructions but not around an asm statement
+  // (cdna_hip_programming.md 5.7).  With the kernel argument left in its SGPR hipcc emitted `v_mov_b32 v, s` right before the statement and
+  // the non-QS loop ran with a wrong c (every gradient ~0.6 N times too large); bisected on the GPU: unpinned fails, unpinned + s_nop pads
+  // passes, pinning only the two values handed to the statements passes (round 5; tests/test_asm_hazards.py refuses the failing shape).
   asm volatile("" : "+v"(c));
   const int nqb = a.N >> 5;
   const int qb_per = nqb / a.qsplit;
@@ -1636,7 +1637,7 @@ __global__ __launch_bounds__(256, 1) void mqa_bwd_fused512a_kernel(AttnArgs a, f
   const uint32_t rowb = __builtin_amdgcn_readfirstlane((uint32_t)(a.H * D) * 4u);
   const uint32_t skof = __builtin_amdgcn_readfirstlane((uint32_t)(2 * kStage + wave * 16384));   // RK - (row-fragment offsets of a stage tile)
   // (floats come out of VALU instructions, and hipcc folds __builtin_amdgcn_readfirstlane of a value it knows to be uniform: an opaque one)
-  auto rfl = [](float x) { uint32_t r; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(r) : "v"(x)); return r; };
+  auto rfl = [](float x) { uint32_t r; asm volatile("s_nop 4\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(r) : "v"(x)); return r; };
   const uint32_t cbits = rfl(c), nrc = rfl(-1.f / c);
   const uint32_t m0base = __builtin_amdgcn_readfirstlane(sb + (uint32_t)wave * 1024u);
   __syncthreads();

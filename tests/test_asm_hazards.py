@@ -28,25 +28,20 @@ def test_asm_mfma_kernels_have_no_unpadded_hazards(tmp_path):
         lint = subprocess.run([sys.executable, str(ROOT / "tools" / "check_mfma_hazards.py"), inst, str(asm)], capture_output=True, text=True)
         assert lint.returncode == 0, lint.stdout[-3000:]
         assert "128 MFMAs checked, 0 finding(s)" in lint.stdout, lint.stdout[-500:]
-    # round 5: the loop kernels hand c and -1/c to their asm statement through inline-asm v_readfirstlane statements.  With the value left in a
-    # scalar register hipcc put the v_mov that materialises it DIRECTLY in front of that v_readfirstlane and the loop ran with wrong row
-    # constants (csrc/attn.hip, mqa_bwd_fused512a_kernel; the mechanism was not identified -- two builds differing only in where c lives): the
-    # shipped source pins c into a vector register first, and this lint refuses the failing shape (v_mov from an SGPR right before the statement)
+    # round 5: the loop kernel hands c and -1/c to its asm statement through inline-asm v_readfirstlane statements.  A vector write of the source
+    # register directly in front of such a statement is a hazard the compiler pads for its own instructions only: with the kernel argument left
+    # in an SGPR hipcc put `v_mov_b32 v, s` right there and the loop ran with a wrong c (bisected on the GPU: s_nop pads inside the statement
+    # fix it, so does pinning the value into a VGPR earlier; csrc/attn.hip does both).  Every such statement must carry its pads.
     lines = [l.strip() for l in asm.read_text().split("\n")]
     for sym in ("_Z24mqa_bwd_fused512a_kernelILb0EEv8AttnArgsPf", "_Z24mqa_bwd_fused512a_kernelILb1EEv8AttnArgsPf"):
-        start = lines.index(sym + ":") if sym + ":" in lines else next(i for i, l in enumerate(lines) if l.startswith(sym + ":"))
+        start = next(i for i, l in enumerate(lines) if l.startswith(sym + ":"))
         end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
-        body = [l for l in lines[start:end] if l and not l.startswith((";", ".")) or l.startswith(";;#ASM")]
+        body = lines[start:end]
         n_rfl = 0
         for i, l in enumerate(body):
-            if l.startswith("v_readfirstlane_b32") and i > 1 and body[i - 1].startswith(";;#ASMSTART"):
+            if l.startswith("v_readfirstlane_b32") and any(x.startswith(";;#ASMSTART") for x in body[max(0, i - 2):i]):
                 n_rfl += 1
-                srcv = l.split(",")[1].strip()
-                prev = body[i - 2]
-                # (a vector RESULT feeding the statement directly is fine -- v_div_fixup does in the shipped build; what failed was the
-                #  kernel argument left in its SGPR and copied by a v_mov in front of the statement)
-                toks = [t.strip() for t in prev.split(" ", 1)[1].split(",")] if " " in prev else []
-                assert not (prev.startswith("v_mov_b32") and toks[0] == srcv and toks[1].startswith("s")), (sym, prev, l)
+                assert body[i - 1].startswith("s_nop") and body[i + 1].startswith("s_nop"), (sym, body[i - 1], l, body[i + 1])
         assert n_rfl >= 2, (sym, n_rfl)
     # the forward kernel keeps its four waves per SIMD (<= 128 VGPRs) WITHOUT scratch since round 4 (one unmasked copy of the tile body);
     # the generated backward loop runs at one wave per SIMD on the whole register file, also without scratch traffic in its loop
