@@ -294,6 +294,12 @@ def main() -> None:
     ap.add_argument("--no-fuse-rowdot", action="store_true", help="A/B: sum(dO*O) by the stand-alone pass instead of the to_out dgrad epilogue")
     args = ap.parse_args()
 
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a five-line version banner to fd 1 at communicator set-up (seen in the
+    # one-rank rehearsal, profiles/r05_rccl_one_rank/), so fd 1 is pointed at stderr for the run and the line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -304,7 +310,16 @@ def main() -> None:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # OSUF_DIST_REHEARSE=1 at N = 1: a ONE-rank process group, so that communicator set-up, the bucketed async all-reduces beside the backward and
+    # the comm diagnostics below run through RCCL on a 1-GPU box (no bytes cross a link; everything else is the N > 1 code path)
+    rehearse = world == 1 and os.environ.get("OSUF_DIST_REHEARSE") == "1"
+    if rehearse:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    dist_on = world > 1 or rehearse
+    if dist_on:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
         else:
@@ -334,7 +349,7 @@ def main() -> None:
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -351,13 +366,13 @@ def main() -> None:
     sync()
     elapsed = time.perf_counter() - t0
     ops.set_kernel_timer(None)
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
 
     comm = None
-    if world > 1:
+    if dist_on:
         # what a first multi-GPU run needs to diagnose itself: what the reducer did in the last timed step on this rank, the same over
         # all ranks, and the gradient all-reduce ALONE (all buckets back to back on an idle GPU: the xGMI-bound part of a step)
         comm = trainer.comm_stats()
@@ -379,7 +394,7 @@ def main() -> None:
         nbytes = trainer.flat.grad.numel() * trainer.flat.grad.element_size()
         comm.update(per_rank=per_rank, devices_visible=torch.cuda.device_count(), device=torch.cuda.get_device_name(device),
                     allreduce_alone_ms=round(1e3 * alone_t.item(), 3),
-                    allreduce_alone_busbw_gbs=round(2 * (world - 1) / world * nbytes / alone_t.item() / 1e9, 1),
+                    allreduce_alone_busbw_gbs=round(2 * (world - 1) / world * nbytes / alone_t.item() / 1e9, 1), rehearsal=rehearse,
                     fingerprints_agree=len({r["layout_fingerprint"] for r in per_rank}) == 1)
     if rank == 0:
         print(f"[bench] timed region done: {1e3 * elapsed / args.steps:.1f} ms/step", file=sys.stderr, flush=True)
@@ -420,7 +435,7 @@ def main() -> None:
             "config": {"workload": (f"trainer_peft path: frozen base + DoRA r={args.lora} on attn.to_q/to_kv/block1.proj/block2.proj "
                                     f"({trainer.flat.numel / 1e6:.1f}M trainable); " if args.lora else "") +
                                    f"full OsuFusion UNet dim_h={args.dim_h} (343.5M params) train step: fwd+bwd+grad-norm+clip+AdamW"
-                                   f"{'+RCCL all-reduce' if world > 1 else ''}, per-GPU batch {args.batch}, L={args.length}, x (B,6,L), "
+                                   f"{'+RCCL all-reduce' if world > 1 else '+one-rank RCCL all-reduce (rehearsal)' if rehearse else ''}, per-GPU batch {args.batch}, L={args.length}, x (B,6,L), "
                                    f"audio (B,96,L) [BASELINE 'audio-ctx=1024x128' maps to the (B,1024,L/8) bottleneck code]",
                        "global_batch": args.batch * world, "seq_len": args.length, "parallelism": f"dp{world}"},
             "loss": round(loss.item(), 5), "grad_norm": round(gnorm.item(), 4),
@@ -479,8 +494,9 @@ def main() -> None:
             print("[bench] config 5: DoRA r=16 steps at the per-GPU shard B=64 ...", file=sys.stderr, flush=True)
             del trainer
             guarded("config5", lambda: config5_secondary(model, rank, device))      # LAST: wraps the model's layers in place
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -15,6 +15,7 @@ MI355X-first choices (nothing here mirrors accelerate/DDP's object model):
 from __future__ import annotations
 
 import math
+import os
 import time
 from typing import List, Optional
 
@@ -107,7 +108,8 @@ class GradReducer:
         self.staging = torch.empty(flat.numel, dtype=self.comm_dtype, device=flat.grad.device) if self.comm_dtype is not None else None
         self._staged: List[int] = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.enabled = self.world > 1
+        # OSUF_DIST_REHEARSE=1: run the whole reduction path on a ONE-rank group too (a 1-GPU box's rehearsal of the RCCL leg)
+        self.enabled = self.world > 1 or (dist.is_initialized() and os.environ.get("OSUF_DIST_REHEARSE") == "1")
         self.sync = True                                   # False during no-sync accumulation micro-steps
         self.handles = []
         self._seen = set()

@@ -115,3 +115,44 @@ def test_bench_main_with_ranks(tmp_path, world):
     assert comm["allreduce_calls"] == comm["buckets"] >= 1 and comm["allreduce_bytes"] > 0
     assert all(r["allreduce_bytes"] == comm["allreduce_bytes"] for r in comm["per_rank"])
     assert comm["allreduce_alone_ms"] > 0 and comm["order_disagreements"] == 0
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("grad_comm", ["fp32", "bf16"])
+def test_bench_one_rank_rccl_rehearsal(grad_comm):
+    """The RCCL leg itself on this one-GPU box: OSUF_DIST_REHEARSE=1 makes bench.py open a ONE-rank `nccl` (= RCCL) process group and run the
+    N > 1 code path unchanged -- communicator set-up with device_id, the bucketed async all-reduces issued beside the backward from the
+    gradient-complete hooks, finish()'s waits, the comm diagnostics and the stand-alone all-reduce timing.  No byte crosses a link, so this says
+    nothing about xGMI rates; it does say that every call the 8-GPU run makes into torch.distributed's RCCL backend is accepted and ordered
+    (trainer.py:264-269,301).  The same small step without the group gives the same loss."""
+    import math
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    args = [sys.executable, str(root / "bench.py"), "--steps", "2", "--warmup", "2", "--dim-h", "96", "--length", "256", "--batch", "2",
+            "--no-sampler", "--no-cpu-baseline", "--no-config5", "--no-fp32-mode", "--grad-comm", grad_comm]
+
+    def run(extra):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), **extra)
+        env.pop("OSUF_DIST_BACKEND", None)
+        if not extra:
+            env.pop("OSUF_DIST_REHEARSE", None)
+        r = subprocess.run(args, env=env, cwd=root, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+
+    out, plain = run({"OSUF_DIST_REHEARSE": "1"}), run({})
+    comm = out["comm"]
+    assert "comm" not in plain and out["n_gpus"] == 1 and comm["rehearsal"] is True
+    assert comm["backend"] == "nccl" and comm["world"] == 1 and comm["fingerprints_agree"]
+    assert comm["comm_dtype"] == ("bfloat16" if grad_comm == "bf16" else "float32")
+    assert comm["allreduce_calls"] == comm["buckets"] >= 1 and comm["out_of_order_completions"] == 0 and comm["order_disagreements"] == 0
+    per_el = 2 if grad_comm == "bf16" else 4
+    assert comm["allreduce_bytes"] % per_el == 0 and comm["allreduce_bytes"] > 0 and comm["allreduce_alone_ms"] > 0
+    assert math.isfinite(out["loss"]) and math.isfinite(out["grad_norm"])
+    # a one-rank SUM is the identity (bf16 buckets: one rounding of every gradient element): same step as without the group
+    assert abs(out["loss"] - plain["loss"]) <= 2e-3 * abs(plain["loss"]) + 1e-5
+    assert abs(out["grad_norm"] - plain["grad_norm"]) <= (2e-2 if grad_comm == "bf16" else 1e-2) * plain["grad_norm"]
