@@ -177,14 +177,20 @@ struct KVStageInc {
     }
     stepk = 64 * a.ldk; stepv = 64 * a.ldv;
   }
+  template <bool WHOLE = false>                                            // WHOLE: N % 64 == 0, no row of any tile lies beyond N (no zero fill, no exec mask)
   __device__ __forceinline__ void load(const AttnArgs& a, int key0) {      // tiles in order: key0 = 0, 64, 128, ...
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      u32x4 z = {0u, 0u, 0u, 0u};
-      rk[i] = z; rv[i] = z;
-      if (key0 + row[i] < a.N) {
+      if constexpr (WHOLE) {
         rk[i] = *reinterpret_cast<const u32x4*>(pk[i]);
         rv[i] = *reinterpret_cast<const u32x4*>(pv[i]);
+      } else {
+        u32x4 z = {0u, 0u, 0u, 0u};
+        rk[i] = z; rv[i] = z;
+        if (key0 + row[i] < a.N) {
+          rk[i] = *reinterpret_cast<const u32x4*>(pk[i]);
+          rv[i] = *reinterpret_cast<const u32x4*>(pv[i]);
+        }
       }
       pk[i] += stepk; pv[i] += stepv;
     }
@@ -206,7 +212,8 @@ struct KVStageInc {
 // ------------------------------------------------------------------------------------------------------
 // QS (queries pre-scaled by scale * log2 e, osuf_mqa_fwd_qs): the scores ARE the exponents, so the running maximum rides the S chain as its C
 // operand (S' = K Qs^T - m_run: 16 registers that change only when a row is rescaled) and p = exp2(S') needs no per-element fma
-template <int NW, bool QS = false>
+// WHOLE (N % 64 == 0): the K / V loads carry no bounds check and there is no masked copy of the tile body
+template <int NW, bool QS = false, bool WHOLE = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][K 8K | V 8K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
   const int ntiles = (a.N + 63) >> 6;
   KVStageInc<NW * 64> st;
   st.init(a, b, tid);
-  st.load(a, 0);
+  st.template load<WHOLE>(a, 0);
   st.store(smem, smem + 8192, tid);
   __syncthreads();
   // one 64-key tile; MASK only for a ragged last tile (a branch-free mask on every tile costs 64 VALU ops per tile)
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
     const char* ks_ = smem + (j & 1) * 16384;
     const char* vs_ = ks_ + 8192;
 #ifndef OSUF_FWD_TRIAGE_NOLOAD
-    if (j + 1 < ntiles) st.load(a, (j + 1) * 64);
+    if (j + 1 < ntiles) st.template load<WHOLE>(a, (j + 1) * 64);
 #endif
     // S^T = K Q^T  (two 32-key tiles)
     f32x16 s[2];
@@ -358,10 +365,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
     __syncthreads();
 #endif
   };
-  const bool ragged = (a.N & 63) != 0;
+  const bool ragged = !WHOLE && (a.N & 63) != 0;
   const int nfull = ragged ? ntiles - 1 : ntiles;                   // one unmasked copy of the tile body: with a loop AND a peeled unmasked twin
   for (int j = 0; j < nfull; ++j) tile(j, std::false_type{});      // hipcc spilled 200 B per lane around the twins (round 4: 128 -> 122 VGPRs, no scratch)
-  if (ragged) tile(ntiles - 1, std::true_type{});
+  if constexpr (!WHOLE) { if (ragged) tile(ntiles - 1, std::true_type{}); }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (qok) {
     const float inv = 1.f / l_tot;
@@ -1913,8 +1920,14 @@ static int mqa_fwd_impl(const void* q, long ldq, const void* k, long ldk, const 
     else hipLaunchKernelGGL(mqa_gen_fwd_kernel<128>, grid, dim3(256), 2 * 64 * 256, stream, a, head_dim);
     return osuf_launch_status();
   }
-  if (qs && getenv("OSUF_ATTN_FWD_NOQSK") == nullptr) hipLaunchKernelGGL((mqa_fwd_kernel<8, true>), dim3((nvb + 7) / 8, B), dim3(512), 32768 + 8 * 4096, stream, a);
-  else hipLaunchKernelGGL(mqa_fwd_kernel<8>, dim3((nvb + 7) / 8, B), dim3(512), 32768 + 8 * 4096, stream, a);
+  const bool whole = (N & 63) == 0 && getenv("OSUF_ATTN_FWD_NOWHOLE") == nullptr;
+  const dim3 grid((nvb + 7) / 8, B);
+  const int lds = 32768 + 8 * 4096;
+  if (qs && getenv("OSUF_ATTN_FWD_NOQSK") == nullptr) {
+    if (whole) hipLaunchKernelGGL((mqa_fwd_kernel<8, true, true>), grid, dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL((mqa_fwd_kernel<8, true>), grid, dim3(512), lds, stream, a);
+  } else if (whole) hipLaunchKernelGGL((mqa_fwd_kernel<8, false, true>), grid, dim3(512), lds, stream, a);
+  else hipLaunchKernelGGL(mqa_fwd_kernel<8>, grid, dim3(512), lds, stream, a);
   return osuf_launch_status();
 }
 

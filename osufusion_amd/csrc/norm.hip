@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* dh, long ldd
 // ------------------------------------------------------------------------------------------------
 static constexpr int kMaxCh = 4;
 
-template <typename T>
+template <typename T, int NCH>                                // NCH: chunks of 8 channels per lane, as in ln_bwd_kernel (86 -> 8 waves per SIMD at NCH = 1)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, long ldx, T* out, long ldo, float* mr, const float* gamma,
                                                      const float* beta, int M, int C, int G) {
   const int chunks = C >> 3;
@@ -302,10 +302,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, long ldx, T* ou
   for (long m0 = (long)wave_global * rows_per_wave; m0 < M; m0 += (long)waves_total * rows_per_wave) {
     const long m = m0 + gr;
     const bool rok = m < M;
-    float v[kMaxCh][8];
+    float v[NCH][8];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < kMaxCh; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       const int ch = gl + j * G;
       if (rok && ch < chunks) {
         load8(x + m * ldx + ch * 8, v[j]);
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, long ldx, T* ou
     const float mean = s * invC;
     float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < kMaxCh; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       const int ch = gl + j * G;
       if (ch < chunks) {
 #pragma unroll
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, long ldx, T* ou
     if (rok) {
       if (gl == 0 && mr) { mr[2 * m] = mean; mr[2 * m + 1] = rstd; }
 #pragma unroll
-      for (int j = 0; j < kMaxCh; ++j) {
+      for (int j = 0; j < NCH; ++j) {
         const int ch = gl + j * G;
         if (ch < chunks) {
           float g[8], bt[8], o[8];
@@ -348,8 +348,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* x, long ldx, T* ou
 }
 
 // dx = rstd * (g*dy - mean_c(g*dy) - xhat * mean_c(g*dy*xhat));  dgamma += sum_m dy*xhat; dbeta += sum_m dy
-template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, const T* x, long ldx, T* dx, long lddx, const float* mr,
+// NCH = chunks of 8 channels per lane (1, 2 or 4): sized by the template, not by NCH -- with the arrays of four chunks the C = 256 LayerNorms of the
+// UNet (one chunk per lane) ran at 176 VGPRs = two waves per SIMD with one pair of rows in flight per wave, i.e. at the latency of its loads (57.7 us for
+// 201 MB); at NCH = 1 the kernel fits eight waves per SIMD
+// NT = threads per block: the per-block dgamma / dbeta atomics all land on the same 2 C addresses and cost ~18 ns per block (measured: 512 / 1024 / 2048 /
+// 4096 blocks of 256 threads 64 / 57 / 75 / 113 us at M = 131,072, C = 256), so the waves that hide the load latency come from FEWER, larger blocks
+template <typename T, int NCH, int NT = 256>
+__global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* dy, long lddy, const T* x, long ldx, T* dx, long lddx, const float* mr,
                                                      const float* gamma, float* dgamma, float* dbeta, int M, int C, int G) {
   const int chunks = C >> 3;
   const int rows_per_wave = 64 / G;
@@ -357,19 +362,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, con
   const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int waves_total = (gridDim.x * blockDim.x) >> 6;
   const float invC = 1.f / (float)C;
-  float ag[kMaxCh][8], ab[kMaxCh][8];
+  float ag[NCH][8], ab[NCH][8];
 #pragma unroll
-  for (int j = 0; j < kMaxCh; ++j)
+  for (int j = 0; j < NCH; ++j)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; }
   for (long m0 = (long)wave_global * rows_per_wave; m0 < M; m0 += (long)waves_total * rows_per_wave) {
     const long m = m0 + gr;
     const bool rok = m < M;
     const float mean = rok ? mr[2 * m] : 0.f, rstd = rok ? mr[2 * m + 1] : 0.f;
-    float xh[kMaxCh][8], gd[kMaxCh][8];
+    float xh[NCH][8], gd[NCH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < kMaxCh; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       const int ch = gl + j * G;
       if (rok && ch < chunks) {
         float xv[8], dv[8], g[8];
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, con
     s2 = group_sum_dyn(s2, G) * invC;
     if (rok) {
 #pragma unroll
-      for (int j = 0; j < kMaxCh; ++j) {
+      for (int j = 0; j < NCH; ++j) {
         const int ch = gl + j * G;
         if (ch < chunks) {
           float o[8];
@@ -409,16 +414,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, con
   // block's 4 waves through LDS, then ONE atomic per channel per block (the grid is capped at 256 blocks by the host)
   for (int o = G; o < 64; o <<= 1) {
 #pragma unroll
-    for (int j = 0; j < kMaxCh; ++j)
+    for (int j = 0; j < NCH; ++j)
 #pragma unroll
       for (int e = 0; e < 8; ++e) { ag[j][e] += __shfl_xor(ag[j][e], o, 64); ab[j][e] += __shfl_xor(ab[j][e], o, 64); }
   }
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem);                 // [4 waves][2][C]
+  float* red = reinterpret_cast<float*>(smem);                 // [NT / 64 waves][2][C]
   const int wave = threadIdx.x >> 6;
   if (gr == 0) {
 #pragma unroll
-    for (int j = 0; j < kMaxCh; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       const int ch = gl + j * G;
       if (ch < chunks) {
 #pragma unroll
@@ -429,7 +434,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* dy, long lddy, con
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
     const int w = i / C, cc = i - w * C;
-    const float s = red[(0 * 2 + w) * C + cc] + red[(1 * 2 + w) * C + cc] + red[(2 * 2 + w) * C + cc] + red[(3 * 2 + w) * C + cc];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) s += red[(k * 2 + w) * C + cc];
     atomic_add_f32((w == 0 ? dgamma : dbeta) + cc, s);
   }
 }
@@ -774,7 +781,7 @@ extern "C" int osuf_gn_bwd(int dtype, const void* dh, long lddh, const void* y, 
   const int B = M / L;
   const int chunks = C / 8;
   const int rp = 256 / chunks;
-  const int rows_per_block = 64;
+  const int rows_per_block = 64;                           // (16 / 32 / 128 measured: within +-3 us of 64 at every level shape, 16 much slower)
   if ((dyy && !dbias) || ((dgamma == nullptr) != (dbeta == nullptr))) return OSUF_EINVAL;
   const size_t lds = (size_t)4 * rp * C * sizeof(float);
   const float inv_count = 1.0f / ((float)L * (float)C);
@@ -794,8 +801,10 @@ extern "C" int osuf_ln_fwd(int dtype, const void* x, long ldx, void* out, long l
                            int M, int C, hipStream_t stream) {
   if (bad_c(C) || M <= 0 || ldx % 8 || ldo % 8) return OSUF_EINVAL;
   const int G = pick_group(C / 8);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(ln_fwd_kernel<T>, dim3(row_grid(M, G)), dim3(256), 0, stream, (const T*)x, ldx, (T*)out, ldo,
-                                       mr, gamma, beta, M, C, G));
+  const int nch = (C / 8 + G - 1) / G;
+#define LN_FWD_LAUNCH(NCH_) hipLaunchKernelGGL((ln_fwd_kernel<T, NCH_>), dim3(row_grid(M, G)), dim3(256), 0, stream, (const T*)x, ldx, (T*)out, ldo, mr, gamma, beta, M, C, G)
+  DISPATCH_T(dtype, if (nch == 1) LN_FWD_LAUNCH(1); else if (nch == 2) LN_FWD_LAUNCH(2); else LN_FWD_LAUNCH(4));
+#undef LN_FWD_LAUNCH
   return osuf_launch_status();
 }
 
@@ -803,10 +812,19 @@ extern "C" int osuf_ln_bwd(int dtype, const void* dy, long lddy, const void* x, 
                            const float* gamma, float* dgamma, float* dbeta, int M, int C, hipStream_t stream) {
   if (bad_c(C) || M <= 0 || ldx % 8 || lddy % 8 || lddx % 8) return OSUF_EINVAL;
   const int G = pick_group(C / 8);
-  long blocks = row_grid(M, G);
-  if (blocks > 512) blocks = 512;                     // bounds the dgamma/dbeta atomic traffic (one atomic / channel / block)
-  DISPATCH_T(dtype, hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3((int)blocks), dim3(256), (size_t)8 * C * sizeof(float), stream, (const T*)dy, lddy, (const T*)x, ldx,
-                                       (T*)dx, lddx, mr, gamma, dgamma, dbeta, M, C, G));
+  const int nch = (C / 8 + G - 1) / G;                // chunks per lane: 1 (C <= 512), 2 (<= 1024), 3 or 4 (<= 2048)
+  // one chunk per lane: 1,024 threads; two: 512 (the LDS reduction holds NT / 64 x 2 C floats <= 64 KiB); OSUF_LN_BWD_SMALLBLOCKS=1 = 256 everywhere (A/B)
+  const int nt = getenv("OSUF_LN_BWD_SMALLBLOCKS") != nullptr ? 256 : nch == 1 ? 1024 : nch == 2 ? 512 : 256;
+  long blocks = (M + (nt / 64) * (64 / G) - 1) / ((nt / 64) * (64 / G));
+  const char* cap_env = getenv("OSUF_LN_BWD_BLOCKS");
+  const long cap = cap_env ? atol(cap_env) : (nt == 256 || (nt == 512 && M >= 32768)) ? 512 : 256;   // bounds the dgamma / dbeta atomics (one per channel and block)
+  if (blocks > cap) blocks = cap;
+  const size_t lds = (size_t)(nt / 64) * 2 * C * sizeof(float);
+#define LN_BWD_LAUNCH(NCH_, NT_) hipLaunchKernelGGL((ln_bwd_kernel<T, NCH_, NT_>), dim3((int)blocks), dim3(NT_), lds, stream, (const T*)dy, lddy, \
+                                                    (const T*)x, ldx, (T*)dx, lddx, mr, gamma, dgamma, dbeta, M, C, G)
+  DISPATCH_T(dtype, if (nt == 1024) LN_BWD_LAUNCH(1, 1024); else if (nt == 512) LN_BWD_LAUNCH(2, 512); else if (nch == 1) LN_BWD_LAUNCH(1, 256);
+                    else if (nch == 2) LN_BWD_LAUNCH(2, 256); else LN_BWD_LAUNCH(4, 256));
+#undef LN_BWD_LAUNCH
   return osuf_launch_status();
 }
 

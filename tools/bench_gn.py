@@ -1,3 +1,5 @@
+"""GroupNorm(1, C) + FiLM + SiLU forward apply and backward (reduce / finalize / apply), gate_residual, wcolsum at the UNet's four level shapes
+(B = 32): time per call; run under `rocprofv3 --kernel-trace --stats` for the per-kernel split.   python tools/bench_gn.py"""
 import sys
 sys.path.insert(0, "/root/repo")
 import torch
@@ -11,11 +13,16 @@ def timeit(fn, iters=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
 B = 32
-for L, C in ((4096, 256), (1024, 512), (512, 1024)):
-    y = torch.randn(B, L, C, device="cuda").bfloat16(); dh = torch.randn(B, L, C, device="cuda").bfloat16()
-    mr = torch.stack([torch.zeros(B, device="cuda"), torch.ones(B, device="cuda")], 1).contiguous()
-    g = torch.ones(C, device="cuda"); bt = torch.zeros(C, device="cuda"); ss = torch.randn(B, 2 * C, device="cuda") * 0.1
-    t1 = timeit(lambda: ops.gn_apply(y, mr, g, bt, ss, L))
-    t2 = timeit(lambda: ops.gn_bwd(dh, y, mr, g, bt, ss, L))
-    by = B * L * C * 2
-    print(f"L={L} C={C}: gn_apply {t1*1e3:6.1f} us ({2*by/t1/1e6:5.0f} GB/s)   gn_bwd (3 kernels) {t2*1e3:6.1f} us ({5*by/t2/1e6:5.0f} GB/s)")
+for L, C in ((4096, 256), (2048, 512), (1024, 768), (512, 1024)):
+    M = B * L
+    y = torch.randn(M, C, device="cuda").bfloat16(); dh = torch.randn(M, C, device="cuda").bfloat16()
+    g = torch.randn(C, device="cuda"); bt = torch.randn(C, device="cuda"); ss = torch.randn(B, 2 * C, device="cuda") * 0.1
+    mr = ops.gn_stats(y, L)
+    dg = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda"); dbias = torch.zeros(C, device="cuda")
+    gate = torch.rand(B, C, device="cuda")
+    t_f = timeit(lambda: ops.gn_apply(y, mr, g, bt, ss, L))
+    t_b = timeit(lambda: ops.gn_bwd(dh, y, mr, g, bt, ss, L, dg, db, dbias))
+    t_g = timeit(lambda: ops.gate_residual(y, gate, dh, L))
+    by = M * C * 2
+    print(f"B*L={M:6d} C={C:4d}  gn_apply {t_f*1e3:6.1f} us {2*by/t_f/1e6:5.0f} GB/s | gn_bwd (3 kernels) {t_b*1e3:6.1f} us {5*by/t_b/1e6:5.0f} GB/s | "
+          f"gate_residual {t_g*1e3:6.1f} us {3*by/t_g/1e6:5.0f} GB/s", flush=True)

@@ -13,6 +13,7 @@ M = 131072
 SHAPES = [(256, 256, 1), (1152, 256, 1), (1024, 256, 1), (256, 1024, 1), (256, 64, 1), (256, 128, 1), (512, 512, 1), (1024, 1024, 1), (1024, 2048, 1), (256, 256, 3), (768, 768, 3)]
 
 
+VAL = os.environ.get("CHECK_VAL", "1")                    # value the switch is set to (e.g. CHECK_VAR=OSUF_GEMM_BIG_MIN_TILES CHECK_VAL=off: the 128^2 kernel)
 VAR = os.environ.get("CHECK_VAR", "OSUF_GEMM_NO8P")      # the switch under test: "plain" column = switch set (NO8P) / for other switches: unset
 
 
@@ -21,7 +22,7 @@ def run(x, w, out, p8, taps=1, L=None):
         if p8: os.environ.pop("OSUF_GEMM_NO8P", None)
         else: os.environ["OSUF_GEMM_NO8P"] = "1"
     else:
-        if p8: os.environ[VAR] = "1"
+        if p8: os.environ[VAR] = VAL
         else: os.environ.pop(VAR, None)
     if taps == 1:
         ops.gemm_nt(x, w, None, out=out)
