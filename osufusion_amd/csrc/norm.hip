@@ -204,10 +204,12 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* dh, long ld
 //   sum_l dy[b,l,c] = rstd_b * ( gamma_c k_bc T2[b,c] - L * S1_b/cnt - (S2_b/cnt) * T3[b,c] )
 // and (dyy, for the DoRA magnitude gradient, lora_layers.py:86-90) sum_l dy*y with y = xhat/rstd + mean, T4 = sum_l xhat^2:
 //   sum_l dy[b,l,c] y[b,l,c] = ( gamma_c k_bc T1 - a1 T3 - a2 T4 ) + mean_b * sum_l dy[b,l,c]
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* T12, const float* gamma, const float* beta, const float* ss,
-                                                              float* S, float* dss, float* dgamma, float* dbeta, float* dbias, float* dyy,
-                                                              const float* mr, int C, int L, float inv_count) {
-  const int b = blockIdx.x;
+// Round 5: no longer a launch of its own (102 six-microsecond launches per train step) -- EVERY workgroup of gn_bwd_apply_kernel evaluates the two sums of
+// its sample (<= 4 x 1,024 floats from L2, the same order as before: bit-identical S1 / S2) and the first workgroup of each sample (`side`) writes the
+// side outputs.  Returns (S1, S2) to every thread; contains the block's only barrier.
+__device__ __forceinline__ void gn_bwd_sums(const float* T12, const float* gamma, const float* beta, const float* ss, float* S, float* dss, float* dgamma,
+                                            float* dbeta, float* dbias, float* dyy, const float* mr, int b, int C, int L, float inv_count, bool side,
+                                            float& S1_out, float& S2_out) {
   float s1 = 0.f, s2 = 0.f;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const float t1 = T12[((long)b * 4 + 0) * C + c], t2 = T12[((long)b * 4 + 1) * C + c];
@@ -215,10 +217,12 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* T12, 
     const float k = ss ? 1.f + ss[(long)b * 2 * C + c] : 1.f;
     s1 += g * k * t2;
     s2 += g * k * t1;
-    if (dss) { dss[(long)b * 2 * C + c] = g * t1 + bt * t2; dss[(long)b * 2 * C + C + c] = t2; }
-    if (dgamma) {
-      atomic_add_f32(dgamma + c, k * t1);
-      atomic_add_f32(dbeta + c, k * t2);
+    if (side) {
+      if (dss) { dss[(long)b * 2 * C + c] = g * t1 + bt * t2; dss[(long)b * 2 * C + C + c] = t2; }
+      if (dgamma) {
+        atomic_add_f32(dgamma + c, k * t1);
+        atomic_add_f32(dbeta + c, k * t2);
+      }
     }
   }
   __shared__ float r1[4], r2[4];
@@ -229,6 +233,8 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* T12, 
   // dgamma == NULL: y was not normalised at all (Block(norm=False), residual.py:71; the caller passes mean 0, rstd 1, gamma 1, beta 0):
   // no statistics, hence none of their gradient terms
   const float S1 = dgamma ? r1[0] + r1[1] + r1[2] + r1[3] : 0.f, S2 = dgamma ? r2[0] + r2[1] + r2[2] + r2[3] : 0.f;
+  S1_out = S1; S2_out = S2;
+  if (!side) return;
   if (threadIdx.x == 0) { S[2 * b] = S1; S[2 * b + 1] = S2; }
   if (dbias) {
     const float mean = mr[2 * b], rstd = mr[2 * b + 1];
@@ -247,15 +253,18 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* T12, 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* dh, long lddh, const T* y, long ldy, T* dy, long lddy,
                                                            const float* mr, const float* gamma, const float* beta, const float* ss,
-                                                           const float* S, int M, int C, int L, float inv_count, int rows_per_block) {
+                                                           const float* T12, float* S, float* dss, float* dgamma, float* dbeta, float* dbias, float* dyy,
+                                                           int M, int C, int L, float inv_count, int rows_per_block) {
   const int chunks = C >> 3;
   const int b = blockIdx.y;
   const ColGeom cg = col_geom(chunks);
   const int ch = threadIdx.x % cg.cp, rl = threadIdx.x / cg.cp;
+  float S1, S2;
+  gn_bwd_sums(T12, gamma, beta, ss, S, dss, dgamma, dbeta, dbias, dyy, mr, b, C, L, inv_count, blockIdx.x == 0, S1, S2);
   if (rl >= cg.rp) return;
   const int c = ch * 8;
   const float mean = mr[2 * b], rstd = mr[2 * b + 1];
-  const float a1 = S[2 * b] * inv_count, a2 = S[2 * b + 1] * inv_count;
+  const float a1 = S1 * inv_count, a2 = S2 * inv_count;
   float g[8], bt[8], k[8], sh[8];
   load8(gamma + c, g);
   load8(beta + c, bt);
@@ -787,12 +796,11 @@ extern "C" int osuf_gn_bwd(int dtype, const void* dh, long lddh, const void* y, 
   const float inv_count = 1.0f / ((float)L * (float)C);
   DISPATCH_T(dtype, hipLaunchKernelGGL(gn_bwd_reduce_kernel<T>, dim3((L + rows_per_block - 1) / rows_per_block, B), dim3(256), lds,
                                        stream, (const T*)dh, lddh, (const T*)y, ldy, mr, gamma, beta, ss, T123, C, L, rows_per_block));
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, stream, T123, gamma, beta, ss, S, dss, dgamma, dbeta, dbias, dyy, mr,
-                     C, L, inv_count);
   {
-    const int rpb = rp * 8;                                // 8 rows per thread
+    const int rpb = rp * 8;                                // 8 rows per thread; the per-sample sums + side outputs (the former finalize launch) ride along
     DISPATCH_T(dtype, hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3((L + rpb - 1) / rpb, B), dim3(256), 0, stream, (const T*)dh,
-                                         lddh, (const T*)y, ldy, (T*)dy, lddy, mr, gamma, beta, ss, S, M, C, L, inv_count, rpb));
+                                         lddh, (const T*)y, ldy, (T*)dy, lddy, mr, gamma, beta, ss, T123, S, dss, dgamma, dbeta, dbias, dyy,
+                                         M, C, L, inv_count, rpb));
   }
   return osuf_launch_status();
 }

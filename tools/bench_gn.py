@@ -1,4 +1,4 @@
-"""GroupNorm(1, C) + FiLM + SiLU forward apply and backward (reduce / finalize / apply), gate_residual, wcolsum at the UNet's four level shapes
+"""GroupNorm(1, C) + FiLM + SiLU forward apply and backward (reduce, apply with the per-sample finalize folded in), gate_residual, wcolsum at the UNet's four level shapes
 (B = 32): time per call; run under `rocprofv3 --kernel-trace --stats` for the per-kernel split.   python tools/bench_gn.py"""
 import sys
 sys.path.insert(0, "/root/repo")
@@ -24,5 +24,5 @@ for L, C in ((4096, 256), (2048, 512), (1024, 768), (512, 1024)):
     t_b = timeit(lambda: ops.gn_bwd(dh, y, mr, g, bt, ss, L, dg, db, dbias))
     t_g = timeit(lambda: ops.gate_residual(y, gate, dh, L))
     by = M * C * 2
-    print(f"B*L={M:6d} C={C:4d}  gn_apply {t_f*1e3:6.1f} us {2*by/t_f/1e6:5.0f} GB/s | gn_bwd (3 kernels) {t_b*1e3:6.1f} us {5*by/t_b/1e6:5.0f} GB/s | "
+    print(f"B*L={M:6d} C={C:4d}  gn_apply {t_f*1e3:6.1f} us {2*by/t_f/1e6:5.0f} GB/s | gn_bwd (reduce + apply) {t_b*1e3:6.1f} us {5*by/t_b/1e6:5.0f} GB/s | "
           f"gate_residual {t_g*1e3:6.1f} us {3*by/t_g/1e6:5.0f} GB/s", flush=True)
