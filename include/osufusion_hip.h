@@ -103,6 +103,12 @@ int osuf_gn_apply_fwd(int dtype, const void* y, long ldy, void* h, long ldh, con
  * finalises them itself and also writes (mean, rstd) to mr_out[B][2] (needed again by osuf_gn_bwd). */
 int osuf_gn_apply_fwd_stats(int dtype, const void* y, long ldy, void* h, long ldh, const double* stats, long count, float* mr_out,
                             const float* gamma, const float* beta, const float* ss, int M, int C, int L, hipStream_t stream);
+/* The bit-reproducible statistics without their second launch: osuf_gn_stats_parts is stage 1 of osuf_gn_stats alone (per-chunk sums into
+ * partial[B][osuf_gn_stats_workspace_bytes / 16][2]); osuf_gn_apply_fwd_parts adds a sample's chunks in a fixed order inside the apply kernel
+ * (every wave the same order: same bits in every workgroup) and also writes (mean, rstd) to mr_out[B][2].  The sampling loop's path since round 5. */
+int osuf_gn_stats_parts(int dtype, const void* y, long ldy, double* partial, int M, int C, int L, hipStream_t stream);
+int osuf_gn_apply_fwd_parts(int dtype, const void* y, long ldy, void* h, long ldh, const double* partial, float* mr_out,
+                            const float* gamma, const float* beta, const float* ss, int M, int C, int L, hipStream_t stream);
 /* T1234 [B][4][C] fp32 zeroed scratch; S [B][2] scratch; dss [B][2C] (may be NULL); dgamma/dbeta accumulated into; dbias (may be
  * NULL): gradient of the bias of the conv that produced y (= column sums of dy, residual.py:77 `self.proj`), accumulated into;
  * dyy (may be NULL, needs dbias): column sums of dy*y -- the DoRA magnitude gradient's numerator (lora_layers.py:86-90).

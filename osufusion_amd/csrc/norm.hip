@@ -82,7 +82,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const T* y, long ldy, T* h, long ldh, const float* mr,
                                                            const float* gamma, const float* beta, const float* ss,
                                                            int M, int C, int L, int rows_per_block,
-                                                           const double* stats, double inv_count, float* mr_out) {
+                                                           const double* stats, double inv_count, float* mr_out, int nparts) {
   // grid (row blocks of one sample, sample): a thread keeps ONE 8-channel chunk and walks rows, so gamma / beta / scale / shift /
   // mean / rstd are loaded once per thread and no index division runs per element (the flat idx / chunks, m / L form spent more
   // VALU on 64-bit divisions and operand reloads than on the normalisation itself)
@@ -90,12 +90,23 @@ __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const T* y, long ldy,
   const int b = blockIdx.y;
   const ColGeom cg = col_geom(chunks);
   const int ch = threadIdx.x % cg.cp, rl = threadIdx.x / cg.cp;
-  if (rl >= cg.rp) return;
-  const int c = ch * 8;
   float mean, rstd;
-  if (stats) {                                             // (sum, sum of squares) of the sample, as the producing GEMM's epilogue left them:
-    const double m1 = stats[2 * b] * inv_count;            // finalised here (what osuf_gn_finalize computes: 102 tiny launches per step less)
-    double var = stats[2 * b + 1] * inv_count - m1 * m1;
+  if (stats) {                                             // (sum, sum of squares) of the sample, finalised here (what osuf_gn_finalize computes):
+    double t1, t2;
+    if (nparts > 0) {
+      // osuf_gn_apply_fwd_parts (the sampler's bit-reproducible path): stats = osuf_gn_stats_parts' [B][nparts][2] partial sums.  Every wave adds
+      // them in the same fixed order (lane-strided, then the xor butterfly), so all waves of all workgroups hold the same bits -- this replaces
+      // gn_finalize_parts_kernel's one-thread-per-sample serial loop (11 us per launch, 115 launches per DDIM step).  Before the early return
+      // below: the butterfly needs whole waves.
+      const int lane = threadIdx.x & 63;
+      double a1 = 0.0, a2 = 0.0;
+      for (int i = lane; i < nparts; i += 64) { a1 += stats[((long)b * nparts + i) * 2]; a2 += stats[((long)b * nparts + i) * 2 + 1]; }
+      t1 = group_sum_f64(a1); t2 = group_sum_f64(a2);
+    } else {                                               // ... as the producing GEMM's epilogue left them (102 tiny launches per step less)
+      t1 = stats[2 * b]; t2 = stats[2 * b + 1];
+    }
+    const double m1 = t1 * inv_count;
+    double var = t2 * inv_count - m1 * m1;
     if (var < 0.0) var = 0.0;
     mean = (float)m1;
     rstd = (float)(1.0 / sqrt(var + (double)kEps));
@@ -103,6 +114,8 @@ __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const T* y, long ldy,
   } else {
     mean = mr[2 * b]; rstd = mr[2 * b + 1];
   }
+  if (rl >= cg.rp) return;
+  const int c = ch * 8;
   float g[8], bt[8], k[8], sh[8];
   load8(gamma + c, g);
   load8(beta + c, bt);
@@ -756,15 +769,24 @@ extern "C" int osuf_gn_stats(int dtype, const void* y, long ldy, double* partial
   return osuf_launch_status();
 }
 
+// stage 1 of osuf_gn_stats alone: per-(sample, row chunk) partial sums into partial[B][nparts][2], nparts = osuf_gn_stats_workspace_bytes / (16 B);
+// osuf_gn_apply_fwd_parts finishes them inside the apply kernel
+extern "C" int osuf_gn_stats_parts(int dtype, const void* y, long ldy, double* partial, int M, int C, int L, hipStream_t stream) {
+  if (bad_c(C) || M <= 0 || L <= 0 || M % L || ldy % 8 || !partial) return OSUF_EINVAL;
+  const int rpb = (256 / (C / 8)) * 8, nchunk = (L + rpb - 1) / rpb, B = M / L;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nchunk, B), dim3(256), 0, stream, (const T*)y, ldy, partial, C, L, rpb, nchunk));
+  return osuf_launch_status();
+}
+
 static int gn_apply_fwd_launch(int dtype, const void* y, long ldy, void* h, long ldh, const float* mr, const float* gamma, const float* beta,
-                               const float* ss, int M, int C, int L, const double* stats, long count, float* mr_out, hipStream_t stream) {
+                               const float* ss, int M, int C, int L, const double* stats, long count, float* mr_out, hipStream_t stream, int nparts = 0) {
   if (bad_c(C) || M <= 0 || L <= 0 || M % L || ldy % 8 || ldh % 8) return OSUF_EINVAL;
   {
     const int rp = 256 / (C / 8);
     const int rpb = rp * 8;                                // 8 rows per thread
     DISPATCH_T(dtype, hipLaunchKernelGGL(gn_apply_fwd_kernel<T>, dim3((L + rpb - 1) / rpb, M / L), dim3(256), 0, stream,
                                          (const T*)y, ldy, (T*)h, ldh, mr, gamma, beta, ss, M, C, L, rpb, stats,
-                                         stats ? 1.0 / (double)count : 0.0, mr_out));
+                                         stats ? 1.0 / (double)count : 0.0, mr_out, nparts));
   }
   return osuf_launch_status();
 }
@@ -779,6 +801,13 @@ extern "C" int osuf_gn_apply_fwd_stats(int dtype, const void* y, long ldy, void*
                                        const float* gamma, const float* beta, const float* ss, int M, int C, int L, hipStream_t stream) {
   if (!stats || !mr_out || count <= 0) return OSUF_EINVAL;
   return gn_apply_fwd_launch(dtype, y, ldy, h, ldh, nullptr, gamma, beta, ss, M, C, L, stats, count, mr_out, stream);
+}
+/* The same from osuf_gn_stats_parts' partial sums (fixed summation order: bit-reproducible); (mean, rstd) also to mr_out[B][2]. */
+extern "C" int osuf_gn_apply_fwd_parts(int dtype, const void* y, long ldy, void* h, long ldh, const double* partial, float* mr_out,
+                                       const float* gamma, const float* beta, const float* ss, int M, int C, int L, hipStream_t stream) {
+  if (!partial || !mr_out || bad_c(C) || L <= 0) return OSUF_EINVAL;
+  const int rpb = (256 / (C / 8)) * 8, nchunk = (L + rpb - 1) / rpb;
+  return gn_apply_fwd_launch(dtype, y, ldy, h, ldh, nullptr, gamma, beta, ss, M, C, L, partial, (long)L * C, mr_out, stream, nchunk);
 }
 
 // T1234: [B][4][C] fp32, must be zero on entry.  dss may be null (no FiLM).  dgamma / dbeta / dbias (the latter optional: gradient

@@ -620,8 +620,7 @@ class BlockFn(torch.autograd.Function):
             mr = torch.tensor([0.0, 1.0], dtype=torch.float32, device=x.device).repeat(B, 1)
             h = ops.gn_apply(y, mr, gamma, beta, ssc, L)
         elif repro:
-            mr = ops.gn_stats(y, L)
-            h = ops.gn_apply(y, mr, gamma, beta, ssc, L)
+            h, mr = ops.gn_apply_reproducible(y, gamma, beta, ssc, L)         # partial sums, finished in fixed order inside the apply kernel
         else:
             h, mr = ops.gn_apply_from_stats(y, stats, gamma, beta, ssc, L)       # the epilogue's raw sums are finalised in the kernel
         ctx.save_for_backward(x, w, y, mr, gamma, beta, ssc if ssc is not None else mr)

@@ -303,6 +303,20 @@ def gn_stats(y: torch.Tensor, L: int) -> torch.Tensor:
     return mr
 
 
+def gn_apply_reproducible(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ss: Optional[torch.Tensor], L: int):
+    """Bit-reproducible statistics + apply in two launches (the sampler): per-chunk partial sums, then the apply kernel adds them in a fixed
+    order itself -> (h, mean_rstd (B, 2)).  Same result on every call; not the same bits as gn_stats' serial second stage."""
+    M, C, ld = _rows(y)
+    B = M // L
+    need = _lib.load().osuf_gn_stats_workspace_bytes(M, C, L)
+    part = torch.empty(max(need // 8, 1), dtype=torch.float64, device=y.device)
+    h = torch.empty(y.shape, dtype=y.dtype, device=y.device)
+    mr = torch.empty((B, 2), dtype=torch.float32, device=y.device)
+    call("osuf_gn_stats_parts", dt_of(y), _p(y), ld, _p(part), M, C, L, _stream())
+    call("osuf_gn_apply_fwd_parts", dt_of(y), _p(y), ld, _p(h), C, _p(part), _p(mr), _p(gamma), _p(beta), _p(ss), M, C, L, _stream())
+    return h, mr
+
+
 def gn_apply_from_stats(y: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, ss: Optional[torch.Tensor], L: int):
     """gn_finalize + gn_apply in one launch: stats (B, 2) fp64 raw sums from the GEMM epilogue -> (h, mean_rstd (B, 2))."""
     M, C, ld = _rows(y)

@@ -259,6 +259,16 @@ def test_reproducible_reductions_vs_atomic_ones():
         rstd = (yy.float().var(dim=(1, 2), unbiased=False) + 1e-5).rsqrt()
         assert torch.allclose(mr[:, 0], mean, atol=1e-5) and torch.allclose(mr[:, 1], rstd, rtol=1e-5)
         assert torch.equal(mr, ops.gn_stats(yy, L))
+        # round 5: the second stage inside the apply kernel (osuf_gn_stats_parts + osuf_gn_apply_fwd_parts, the sampler's path): same statistics
+        # (another fixed summation order: equal to rounding), same output as the two-kernel form fed those statistics, identical bits on every call
+        g, bt = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+        ss = torch.randn(Bn, 2 * C, device=DEV) * 0.1
+        for s_ in (ss, None):
+            h2, mr2 = ops.gn_apply_reproducible(yy.reshape(Bn * L, C), g, bt, s_, L)
+            assert torch.allclose(mr2, mr, rtol=1e-6, atol=1e-7)
+            assert torch.equal(h2, ops.gn_apply(yy.reshape(Bn * L, C), mr2, g, bt, s_, L))
+            h3, mr3 = ops.gn_apply_reproducible(yy.reshape(Bn * L, C), g, bt, s_, L)
+            assert torch.equal(h2, h3) and torch.equal(mr2, mr3)
         w = torch.rand(Bn * L, device=DEV)
         want = (yy.float() * w.view(Bn, L, 1)).sum(1)
         atomic = ops.wcolsum(yy, None, w, Bn, L)
