@@ -131,9 +131,9 @@ def _cpu_baseline_at(model, length: int, threads: int, warm: int = 3, timed: int
         loss.backward()
         times.append(time.perf_counter() - t0)
         print(f"[bench] cpu_baseline: iteration {it} fwd+bwd {times[-1]:.1f} s", file=sys.stderr, flush=True)
-        if give_up_above is not None and it == 1 and min(times) > give_up_above:
-            gave_up = True                                 # second iteration (the first pays one-time allocations) and still slower: oversubscribed
-            break
+        if give_up_above is not None and ((it == 0 and times[0] > 3.0 * give_up_above) or (it == 1 and min(times) > give_up_above)):
+            gave_up = True                                 # the first iteration pays one-time allocations: give up on it alone only when it is several times
+            break                                          # slower (128 threads on a 16-CPU share: 20 s against 2.9), else after the second: oversubscribed
     if gave_up:
         dt, how = min(times), f"best of {len(times)} iterations, not pursued: slower than the smaller thread count"
     else:
