@@ -39,6 +39,8 @@ extern "C" {
 #define OSUF_DQ_ATOMIC_512 3      /* force the 4-wave, 512-key sweep (whole 512-key blocks: N % 512 == 0, else OSUF_EUNSUPPORTED) */
 #define OSUF_DQ_ATOMIC_512A 5     /* the 512-key sweep with its hand-placed loop (tools/gen_attn_bwd512.py): dK / dV bit-identical to
                                      OSUF_DQ_ATOMIC_512; whole 512-key blocks and an even number of (head, query block) pairs per part */
+#define OSUF_DQ_PREZEROED 0x100   /* flag, OR-ed into an atomic dq_mode: the dQ accumulator at the head of `workspace` was zero-filled by
+                                     osuf_mqa_fwd_zdq of the same layer (the entry point then issues no memset) */
 #define OSUF_DQ_TIMING_512 4      /* DEBUG: the 512-key sweep WITHOUT its atomics (prices the loop; dq comes back zero) -- refused with
                                      OSUF_EUNSUPPORTED unless the process environment holds OSUF_ALLOW_TIMING_BUILDS=1 */
 
@@ -165,6 +167,11 @@ int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, const void* v
  * replaces: F.scaled_dot_product_attention at attention.py:94-99 (as osuf_mqa_fwd). */
 int osuf_mqa_fwd_qs(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
                     float* lse2, int B, int H, int N, int head_dim, float scale, hipStream_t stream);
+/* osuf_mqa_fwd (qs = 0) / osuf_mqa_fwd_qs (qs = 1) that also zero-fills zero_dq[B*N][H*64] (fp32): the dQ accumulator at the head of the
+ * workspace of this layer's osuf_mqa_bwd_fused* call, which then takes dq_mode | OSUF_DQ_PREZEROED.  The forward loop is bound by the vector
+ * pipe with HBM idle, so the fill costs nothing there; in front of the backward sweep it is 66 us per N = 4096 layer.  head_dim 64 only. */
+int osuf_mqa_fwd_zdq(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
+                     float* lse2, int B, int H, int N, int head_dim, float scale, int qs, float* zero_dq, hipStream_t stream);
 /* Attend(q, k, v, attn_mask) (attention.py:77-99): the reference casts the mask to bf16 and passes it to SDPA as an additive bias of
  * the scaled scores (so a bool mask adds 1.0 / 0.0 -- kept).  mask: bf16, element strides over (batch, head, query, key), 0 for a
  * broadcast dimension.  Inference only (no backward entry point); all head dims go through the generic kernel.

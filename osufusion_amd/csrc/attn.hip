@@ -120,6 +120,7 @@ struct AttnArgs {
   const float* rcos; const float* rsin;         // [N][32] RoPE tables: when set, dQ / dK are stored as gradients of the UN-rotated q / k
   int B, H, N;
   float scale;
+  float* zdq;                                   // osuf_mqa_fwd_zdq: the backward's fp32 dQ accumulator [B*N][H*64], zero-filled by the forward kernel (null: not)
   float cexp, kmul;                             // exponent multiplier of S (scale * log2 e; 1 when q arrives pre-scaled by it: the *_qs entry points)
                                                 // and the multiplier of the dK sums (scale; scale / cexp = 1 / log2 e for pre-scaled q)
   int qsplit;                                   // dK/dV: > 1 = the query range is cut into qsplit parts (short sequences: more workgroups),
@@ -385,6 +386,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
         if (a.o_is_f32) store4(reinterpret_cast<float*>(a.o) + m * a.ldo + h * D + d0, v4);
         else store4(reinterpret_cast<bf16_t*>(a.o) + m * a.ldo + h * D + d0, v4);
       }
+  }
+  // osuf_mqa_fwd_zdq: this wave's 32 rows x 256 B of the backward's dQ accumulator are cleared here -- the loop above is bound by the vector pipe with
+  // HBM idle (0.16 TB/s), so the 8 stores per wave are free where the hipMemsetAsync in front of the backward sweep cost 66 us per N = 4096 layer
+  if (a.zdq != nullptr && active) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = pb * 32 + i * 4 + (lane >> 4);
+      if (r < a.N) *reinterpret_cast<u32x4*>(a.zdq + ((long)b * a.N + r) * ((long)a.H * D) + h * D + (lane & 15) * 4) = z;
+    }
   }
 }
 
@@ -1894,25 +1905,34 @@ static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 // head dims served by the generic kernels of attn_generic.hpp (64 has the tuned kernels of this file): padded tile width, 0 = unsupported
 static int gen_dp(int head_dim) { return head_dim == 16 || head_dim == 32 ? 32 : head_dim == 128 ? 128 : 0; }
 static int mqa_fwd_impl(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
-                        float* lse2, int B, int H, int N, int head_dim, float scale, bool qs, hipStream_t stream);
+                        float* lse2, int B, int H, int N, int head_dim, float scale, bool qs, hipStream_t stream, float* zdq);
 extern "C" int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
                             float* lse2, int B, int H, int N, int head_dim, float scale, hipStream_t stream) {
-  return mqa_fwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, o_dtype, lse2, B, H, N, head_dim, scale, false, stream);
+  return mqa_fwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, o_dtype, lse2, B, H, N, head_dim, scale, false, stream, nullptr);
 }
 // q holds the rotated queries ALREADY multiplied by scale * log2 e (osuf_rope_cast_qs): the scores leave the MFMA chain in the log2 domain
 extern "C" int osuf_mqa_fwd_qs(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
                                float* lse2, int B, int H, int N, int head_dim, float scale, hipStream_t stream) {
   if (head_dim != D) return OSUF_EUNSUPPORTED;
-  return mqa_fwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, o_dtype, lse2, B, H, N, head_dim, scale, true, stream);
+  return mqa_fwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, o_dtype, lse2, B, H, N, head_dim, scale, true, stream, nullptr);
+}
+// osuf_mqa_fwd (qs = 0) / osuf_mqa_fwd_qs (qs = 1) that ALSO zero-fills zero_dq[B*N][H*64] fp32 -- the first osuf_mqa_bwd_fused_workspace_bytes'
+// dQ accumulator of the layer's backward, which is then called with dq_mode | OSUF_DQ_PREZEROED and skips its memset.  head_dim 64 only.
+extern "C" int osuf_mqa_fwd_zdq(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
+                                float* lse2, int B, int H, int N, int head_dim, float scale, int qs, float* zero_dq, hipStream_t stream) {
+  if (head_dim != D || !zero_dq) return OSUF_EUNSUPPORTED;
+  return mqa_fwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, o_dtype, lse2, B, H, N, head_dim, scale, qs != 0, stream, zero_dq);
 }
 static int mqa_fwd_impl(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
-                        float* lse2, int B, int H, int N, int head_dim, float scale, bool qs, hipStream_t stream) {
+                        float* lse2, int B, int H, int N, int head_dim, float scale, bool qs, hipStream_t stream, float* zdq) {
   if (head_dim != D && !gen_dp(head_dim)) return OSUF_EUNSUPPORTED;
+  if (zdq && (head_dim != D || !al16(zdq))) return OSUF_EINVAL;
   if (B <= 0 || H <= 0 || N <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || !al16(q) || !al16(k) || !al16(v) || !al16(o)) return OSUF_EINVAL;
   AttnArgs a = {};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
   a.o = o; a.ldo = ldo; a.o_is_f32 = o_dtype == OSUF_DT_F32; a.lse2 = lse2; a.B = B; a.H = H; a.N = N; a.scale = scale; a.cexp = scale * kLog2e; a.kmul = scale;
   if (qs) a.cexp = 1.f;
+  a.zdq = zdq;
   const int nvb = ((N + 31) / 32) * H;
   if (head_dim != D) {
     const dim3 grid((nvb + 3) / 4, B);
@@ -2100,6 +2120,11 @@ static int fused512_qsplit(int B, int N, int forced) {
   return sp;
 }
 static bool fused_mode_ok(int dq_mode) { return dq_mode >= OSUF_DQ_ATOMIC && dq_mode <= OSUF_DQ_ATOMIC_512A; }
+// dq_mode | OSUF_DQ_PREZEROED: the dQ accumulator at the head of the workspace was zero-filled by osuf_mqa_fwd_zdq (no memset here)
+static int strip_prezeroed(int dq_mode, bool* prezeroed) {
+  if (prezeroed) *prezeroed = (dq_mode & OSUF_DQ_PREZEROED) != 0;
+  return dq_mode & ~OSUF_DQ_PREZEROED;
+}
 // the hand-placed loop (mqa_bwd_fused512a_kernel) walks the pairs two at a time and carries 32-bit byte offsets from the first row of a
 // sample's query part: whole query parts of an even number of pairs, and every running offset -- Q / dO requests (up to N rows of ldq / lddo
 // elements), dQ atomics (up to N + 32 rows of H * 64 floats: row bases + 16 rows of the second query half + the lane's 4 g4 rows), row
@@ -2116,6 +2141,7 @@ static long fused_dkv_ws_bytes(int B, int N, int qsplit, int dq_mode) {
   return sp > 1 ? 2L * sp * B * N * D * (long)sizeof(float) : 0;
 }
 extern "C" long osuf_mqa_bwd_fused_workspace_bytes(int B, int H, int N, int out_dtype, int qsplit, int dq_mode) {
+  dq_mode = strip_prezeroed(dq_mode, nullptr);
   if (B <= 0 || H <= 0 || N <= 0 || qsplit < 0 || qsplit > 16 || !fused_mode_ok(dq_mode)) return 0;
   return fused_dq_bytes(B, H, N, out_dtype, dq_mode) + fused_dkv_ws_bytes(B, N, qsplit, dq_mode);
 }
@@ -2144,6 +2170,9 @@ static int mqa_bwd_fused_impl(const void* q, long ldq, const void* k, long ldk, 
                               const float* lse2, const float* delta, void* dq, long lddq, void* dk, void* dv, long lddk, int B, int H,
                               int N, int head_dim, float scale, int out_dtype, const float* rope_cos, const float* rope_sin,
                               float* workspace, long workspace_bytes, int qsplit, int dq_mode, bool qs, hipStream_t stream) {
+  bool prezeroed = false;
+  dq_mode = strip_prezeroed(dq_mode, &prezeroed);
+  if (prezeroed && dq_mode == OSUF_DQ_SLABS) return OSUF_EINVAL;     // the slabs are written whole: nothing to pre-zero
   AttnArgs a;
   int rc = fill_bwd_args(a, q, ldq, k, ldk, v, ldv, dout, lddo, lse2, delta, B, H, N, head_dim, scale);
   if (rc) return rc;
@@ -2164,7 +2193,7 @@ static int mqa_bwd_fused_impl(const void* q, long ldq, const void* k, long ldk, 
   a.qsplit = use512 ? fused512_qsplit(B, N, qsplit) : dkv_qsplit(B, N, qsplit);
   if (a.qsplit > 1) { a.wsk = wsp; a.wsv = wsp + (long)a.qsplit * B * N * D; }
   const int b8 = (B + 7) / 8 * 8;
-  if (dq_mode != OSUF_DQ_SLABS) {
+  if (dq_mode != OSUF_DQ_SLABS && !prezeroed) {
     hipError_t e = hipMemsetAsync(dq32, 0, (size_t)dq_bytes, stream);
     if (e != hipSuccess) return (int)e;
   }

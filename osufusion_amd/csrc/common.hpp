@@ -44,6 +44,7 @@ static_assert(sizeof(osuf_linear_desc) == 56, "osuf_linear_desc is part of the C
 #define OSUF_DQ_ATOMIC_512 3      /* force the 4-wave, 512-key sweep (N % 32 == 0) */
 #define OSUF_DQ_TIMING_512 4      /* the 512-key sweep WITHOUT its atomics: timing only, dq is zero */
 #define OSUF_DQ_ATOMIC_512A 5     /* the 512-key sweep with the generated, hand-placed loop (attn_bwd512_asm.inc) */
+#define OSUF_DQ_PREZEROED 0x100   /* flag: the dQ accumulator was zero-filled by osuf_mqa_fwd_zdq (no memset in the backward entry point) */
 
 typedef uint16_t bf16_t;                                   // raw bf16 bits in HBM
 typedef __attribute__((ext_vector_type(4))) float f32x4;

@@ -890,7 +890,7 @@ class AttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, nw, nb, wq, wkv, wo, bo, cache, heads, dim_head, scale_base, aq=None, akv=None,
-                qa=None, qb=None, qm=None, kva=None, kvb=None, kvm=None, kv_heads=1, base=None):
+                qa=None, qb=None, qm=None, kva=None, kvb=None, kvm=None, kv_heads=1, base=None, grad_mode=False):
         # kv_heads = G > 1 (grouped-query attention, unet.py:132-135): the caller hands wq with its head blocks in GROUP-MAJOR order
         # (heads g*H/G .. share K/V head g) and wo with its input columns permuted alike (modules/unet.py Attention._forward_gqa);
         # base = (to_q.weight, to_out.weight): the parameters those two views derive from -- what the pack cache must version on
@@ -907,7 +907,11 @@ class AttentionFn(torch.autograd.Function):
         qs = ops.q_prescale_ok(D, ops.ATTN_BWD_DEFAULT)
         qkv_r = ops.rope_cast(qkv, cos, sin, N, H + G, H + 2 * G, D, q_mul=scale * ops.LOG2E if qs else 1.0, n_q_heads=H)   # rotate q and k heads; cast v
         del qkv
-        o, lse = ops.mqa_fwd(qkv_r, B, N, H, D, dt, scale, kv_heads=G, qs=qs)
+        # a backward will follow: the forward kernel zero-fills the dQ accumulator of this layer's fused backward sweep (private workspace, kept to then)
+        # (grad_mode: the caller's torch.is_grad_enabled() -- needs_input_grad alone is also true under no_grad, e.g. in the sampler)
+        dq_ws = ops.fused_bwd_workspace(B, N, H, D, dt, x.device) if (G == 1 and grad_mode and any(ctx.needs_input_grad)) else None
+        o, lse = ops.mqa_fwd(qkv_r, B, N, H, D, dt, scale, kv_heads=G, qs=qs, zero_dq=dq_ws)
+        ctx.dq_ws = dq_ws
         wpo = cache.packs(("po", dt), (wo,) if base is None else (base[1],), wo, "same", dt)[0]
         out = ops.gemm_nt(o, wpo, bo, residual=xn, out_shape=x.shape)
         ctx.base = base
@@ -955,7 +959,8 @@ class AttentionFn(torch.autograd.Function):
         if ctx.qs and variant not in ops._FUSED_DQ_MODE:                         # the default changed between forward and backward (tests do): the
             variant = ops.ATTN_FUSED                                             # saved queries are pre-scaled, only the fused sweeps read those
         dqkv = ops.mqa_bwd(qkv_r, o, do16, lse, B, N, H, D, scale, dt, cos, sin, variant=variant, delta=delta,
-                           kv_heads=G, qs=ctx.qs)                                # RoPE transpose + cast ride the kernels' epilogues
+                           kv_heads=G, qs=ctx.qs, workspace=ctx.dq_ws)           # RoPE transpose + cast ride the kernels' epilogues
+        ctx.dq_ws = None                                                         # (a second backward through this node falls back to the memset)
         # to_q / to_kv
         dwq = conv_wgrad(dqkv[..., : H * D], xn, wq, "same") if need[3] else None
         dwkv = conv_wgrad(dqkv[..., H * D:], xn, wkv, "same") if need[4] else None
@@ -977,7 +982,7 @@ class AttentionFn(torch.autograd.Function):
             grad_done(nw); grad_done(ctx.nb)
             dnw = dnb = None
         return (dx, dnw if need[1] else None, dnb if need[2] else None, dwq, dwkv, dwo, dbo, None, None, None, None, None, None,
-                *gq, *gkv, None, None)
+                *gq, *gkv, None, None, None)
 
 
 class RowsFromNCLFn(torch.autograd.Function):

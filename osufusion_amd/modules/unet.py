@@ -168,7 +168,7 @@ class Attention(nn.Module):
         x = rt.cast_rows(x.contiguous(), rt.compute_dtype(self.to_q.weight.dtype))
         if self.kv_heads != 1:
             return self._forward_gqa(x)
-        extra = ()
+        extra = (None,) * 8
         if hasattr(self.to_q, "adapter_inputs") or hasattr(self.to_kv, "adapter_inputs"):                # lora_layers.LoraLinear
             none4 = (None, None, None, None)
             aq, qa, qb, qm = self.to_q.adapter_inputs() if hasattr(self.to_q, "adapter_inputs") else none4
@@ -176,7 +176,8 @@ class Attention(nn.Module):
             extra = (aq, akv, qa, qb, qm, ka, kb, km)
         with scope("Attention"):                           # unet.py:144
             return Fn.AttentionFn.apply(x, self.norm.weight, self.norm.bias, self.to_q.weight, self.to_kv.weight, self.to_out.weight,
-                                        self.to_out.bias, self._cache, self.heads, self.dim_head, self.context_len, *extra)
+                                        self.to_out.bias, self._cache, self.heads, self.dim_head, self.context_len, *extra, 1, None,
+                                        torch.is_grad_enabled())       # (grad mode is off inside Function.forward: tell it whether a backward can follow)
 
 
     def _forward_gqa(self, x: torch.Tensor) -> torch.Tensor:
@@ -193,7 +194,7 @@ class Attention(nn.Module):
         with scope("Attention"):                           # unet.py:144
             return Fn.AttentionFn.apply(x, self.norm.weight, self.norm.bias, wq, self.to_kv.weight, wo, self.to_out.bias, self._cache,
                                         H, D, self.context_len, None, None, None, None, None, None, None, None, G,
-                                        (self.to_q.weight, self.to_out.weight))
+                                        (self.to_q.weight, self.to_out.weight), torch.is_grad_enabled())
 
 
 class FeedForward(nn.Sequential):

@@ -7,6 +7,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -166,7 +168,7 @@ def zeros(shape, dtype: torch.dtype, device) -> torch.Tensor:
     return torch.zeros(shape, dtype=dtype, device=device)
 
 
-_TIMED_AS = {"osuf_mqa_fwd_qs": "osuf_mqa_fwd", "osuf_mqa_bwd_fused_qs": "osuf_mqa_bwd_fused"}    # pre-scaled-query forms: timed under the plain name
+_TIMED_AS = {"osuf_mqa_fwd_qs": "osuf_mqa_fwd", "osuf_mqa_fwd_zdq": "osuf_mqa_fwd", "osuf_mqa_bwd_fused_qs": "osuf_mqa_bwd_fused"}    # pre-scaled-query forms: timed under the plain name
 
 
 def call(name: str, *args, meta=None) -> None:
@@ -455,18 +457,43 @@ def rope_bwd(dqkv32: torch.Tensor, out_dtype: torch.dtype, cos, sin, N: int, n_r
     return out
 
 
-def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.dtype, scale: float, kv_heads: int = 1, qs: bool = False):
+DQ_PREZEROED = 0x100                                             # OSUF_DQ_PREZEROED
+
+
+def fused_bwd_workspace(B: int, N: int, H: int, D: int, out_dtype: torch.dtype, device, variant: Optional[int] = None, qsplit: int = 0):
+    """A PRIVATE workspace for one layer's fused attention backward, to be zero-filled by that layer's forward (mqa_fwd(zero_dq=...)) and handed to
+    mqa_bwd(workspace=...): the dQ accumulator's memset (66 us per N = 4096 layer in front of the backward sweep) then rides the forward
+    kernel, which is bound by the vector pipe and leaves HBM idle.  None where the path does not apply (head dim != 64, non-atomic dQ, OSUF_ATTN_NO_ZDQ=1)."""
+    variant = ATTN_BWD_DEFAULT if variant is None else variant
+    if D != 64 or variant not in _FUSED_DQ_MODE or variant in (ATTN_FUSED_SLABS, ATTN_FUSED512_TIMING) or os.environ.get("OSUF_ATTN_NO_ZDQ") == "1":
+        return None
+    need = _lib.load().osuf_mqa_bwd_fused_workspace_bytes(B, H, N, _DT[out_dtype], qsplit, _FUSED_DQ_MODE[variant])
+    if need <= 0:
+        return None
+    ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+    ws.fused_variant = variant                              # the layout (and the zero-filled part) belong to this variant's dq_mode
+    return ws
+
+
+def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.dtype, scale: float, kv_heads: int = 1, qs: bool = False,
+            zero_dq: Optional[torch.Tensor] = None):
     """qkv: bf16 rows [B*N][(H+2G)*D] (q heads | G k heads | G v heads).  Returns o rows [B*N][H*D] and lse2 [B][H][N].
     G = kv_heads > 1 (grouped-query attention, unet.py:135): the q heads are laid out GROUP-MAJOR -- heads g*H/G .. (g+1)*H/G - 1
     share K/V head g -- and every group is one launch of the one-K/V-head kernels on its column block; lse2 is then [G][B][H/G][N].
-    qs: the q columns hold queries pre-scaled by scale * log2 e (rope_cast(q_mul=...))."""
+    qs: the q columns hold queries pre-scaled by scale * log2 e (rope_cast(q_mul=...)).  zero_dq (fused_bwd_workspace): its first B*N*H*D floats
+    -- the backward's dQ accumulator -- are zero-filled by this launch (one K/V head, head dim 64)."""
     M, W, ld = _rows(qkv)
     G = kv_heads
     assert qkv.dtype == torch.bfloat16 and W == (H + 2 * G) * D and H % G == 0
+    assert zero_dq is None or (G == 1 and D == 64 and zero_dq.dtype == torch.float32 and zero_dq.numel() >= B * N * H * D)
     r = H // G
     o = torch.empty((B, N, H * D), dtype=out_dtype, device=qkv.device)
     lse = torch.empty((B, H, N) if G == 1 else (G, B, r, N), dtype=torch.float32, device=qkv.device)
     base, eo = qkv.data_ptr(), o.element_size()
+    if zero_dq is not None:
+        call("osuf_mqa_fwd_zdq", base, ld, base + 2 * H * D, ld, base + 2 * (H + 1) * D, ld, o.data_ptr(), H * D, _DT[out_dtype], lse.data_ptr(), B, H, N, D, scale,
+             1 if qs else 0, zero_dq.data_ptr(), _stream(), meta=LaunchSize(N, B))
+        return o, lse
     for g in range(G):
         call("osuf_mqa_fwd_qs" if qs else "osuf_mqa_fwd", base + 2 * g * r * D, ld, base + 2 * (H + g) * D, ld, base + 2 * (H + G + g) * D, ld, o.data_ptr() + eo * g * r * D,
              H * D, _DT[out_dtype], lse.data_ptr() + 4 * g * B * r * N, B, r, N, D, scale, _stream(), meta=LaunchSize(N, B))
@@ -499,10 +526,12 @@ FUSE_ROWDOT = True      # AttentionFn.backward: sum_d dO * O from the to_out dgr
 
 def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int, D: int, scale: float,
             out_dtype: torch.dtype = torch.float32, cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None,
-            variant: int = ATTN_AUTO, qsplit: int = 0, delta: Optional[torch.Tensor] = None, kv_heads: int = 1, qs: bool = False) -> torch.Tensor:
+            variant: int = ATTN_AUTO, qsplit: int = 0, delta: Optional[torch.Tensor] = None, kv_heads: int = 1, qs: bool = False,
+            workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Gradients laid out like qkv, [B*N][(H+2G)*D], in out_dtype.  With the RoPE tables (N, D/2) the q / k gradients are those of
     the un-rotated projections (the rotation's transpose is applied in the kernels' epilogues).  kv_heads = G > 1: one launch set
-    per group on its column blocks (see mqa_fwd; lse / delta are [G][B][H/G][N])."""
+    per group on its column blocks (see mqa_fwd; lse / delta are [G][B][H/G][N]).  workspace: a fused_bwd_workspace whose dQ accumulator this
+    layer's forward zero-filled (mqa_fwd(zero_dq=...)): used instead of the shared workspace, without the memset."""
     M, W, ld = _rows(qkv)
     G = kv_heads
     r = H // G
@@ -528,7 +557,10 @@ def mqa_bwd(qkv: torch.Tensor, o: torch.Tensor, do: torch.Tensor, lse: torch.Ten
         if variant in _FUSED_DQ_MODE:
             mode = _FUSED_DQ_MODE[variant]
             need = _lib.load().osuf_mqa_bwd_fused_workspace_bytes(B, r, N, _DT[out_dtype], qsplit, mode)
-            ws = _workspace(need, qkv.device)
+            if workspace is not None and G == 1 and getattr(workspace, "fused_variant", None) == variant and workspace.numel() * 4 >= need:
+                ws, mode = workspace, mode | DQ_PREZEROED
+            else:
+                ws = _workspace(need, qkv.device)
             call("osuf_mqa_bwd_fused_qs" if qs else "osuf_mqa_bwd_fused", q_, ld, k_, ld, v_, ld, do_, ldo_, lse_, delta_, dq_, W, dk_, dv_, W, B, r, N, D, scale, _DT[out_dtype],
                  _p(cos), _p(sin), _p(ws), need, qsplit, mode, _stream(), meta=N)
             continue

@@ -6,7 +6,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from osufusion_amd import functional as Fn
-from osufusion_amd import ops
+from osufusion_amd import forced_compute_dtype, ops
 from tests.test_hip_parity import B, DEV, relmax, report
 
 
@@ -178,3 +178,70 @@ def test_attention_with_prescaled_queries(Bn, N, H, G):
         b = ops.mqa_bwd(qkv_r, o, do, lse, Bn, N, H, D, scale, torch.float32, cos, sin, variant=ops.ATTN_FUSED512, kv_heads=G, qs=True)
         assert torch.equal(a[..., H * D:], b[..., H * D:])
         assert ((a[..., : H * D] - b[..., : H * D]).norm() / b[..., : H * D].norm()).item() < 1e-5
+
+
+@pytest.mark.parametrize("Bn,N,H,qs", [(2, 200, 3, False), (1, 512, 2, True), (2, 1024, 4, True), (1, 2048, 16, True), (2, 1024, 1, False)])
+def test_forward_zero_fills_the_backward_dq_accumulator(Bn, N, H, qs):
+    """osuf_mqa_fwd_zdq + dq_mode | OSUF_DQ_PREZEROED: the forward kernel clears the fp32 dQ accumulator of the layer's fused backward sweep (the
+    memset in front of the sweep is gone).  The forward's own results do not change by a bit; exactly the accumulator's B*N*H*64 floats are
+    cleared (a NaN-filled workspace: zeros there, NaN behind); the backward on that workspace equals the memset path -- bit for bit where at most two
+    key blocks add into an element (fp32 addition commutes), to rounding where more do."""
+    D = 64
+    scale = D ** -0.5
+    raw = torch.randn(Bn, N, (H + 2) * D, device=DEV).to(torch.bfloat16)
+    do = torch.randn(Bn, N, H * D, device=DEV).to(torch.bfloat16)
+    cos, sin = Fn.rope_tables(N, D, 2 * N, DEV)
+    qkv_r = ops.rope_cast(raw, cos, sin, N, H + 1, H + 2, D, q_mul=scale * ops.LOG2E if qs else 1.0, n_q_heads=H)
+    o0, lse0 = ops.mqa_fwd(qkv_r, Bn, N, H, D, torch.bfloat16, scale, qs=qs)
+    g0 = ops.mqa_bwd(qkv_r, o0, do, lse0, Bn, N, H, D, scale, torch.float32, cos, sin, variant=ops.ATTN_FUSED, qs=qs)
+    ws = ops.fused_bwd_workspace(Bn, N, H, D, torch.float32, DEV, variant=ops.ATTN_FUSED)
+    assert ws is not None and ws.numel() >= Bn * N * H * D
+    ws.fill_(float("nan"))
+    o1, lse1 = ops.mqa_fwd(qkv_r, Bn, N, H, D, torch.bfloat16, scale, qs=qs, zero_dq=ws)
+    assert torch.equal(o0, o1) and torch.equal(lse0, lse1)
+    n = Bn * N * H * D
+    assert int((ws[:n] != 0).sum().item()) == 0
+    assert ws.numel() == n or bool(torch.isnan(ws[n:]).all())
+    if ws.numel() > n:
+        ws[n:].zero_()                                     # (the dK / dV partial-sum region behind it is written whole by the sweep; keep NaN out of the test's way)
+    g1 = ops.mqa_bwd(qkv_r, o1, do, lse1, Bn, N, H, D, scale, torch.float32, cos, sin, variant=ops.ATTN_FUSED, qs=qs, workspace=ws)
+    assert torch.isfinite(g1).all()
+    if N <= 1024:
+        assert torch.equal(g0, g1)
+    else:
+        assert ((g0 - g1).norm() / g0.norm()).item() < 1e-5
+    # a workspace made for another variant is not trusted: the shared workspace + memset path runs (same result)
+    g2 = ops.mqa_bwd(qkv_r, o1, do, lse1, Bn, N, H, D, scale, torch.float32, cos, sin, variant=ops.ATTN_FUSED256, qs=qs, workspace=ws)
+    g256 = ops.mqa_bwd(qkv_r, o1, do, lse1, Bn, N, H, D, scale, torch.float32, cos, sin, variant=ops.ATTN_FUSED256, qs=qs)
+    assert ((g256 - g2).norm() / g256.norm()).item() < 1e-5 and ((g0 - g2).norm() / g0.norm()).item() < 1e-3
+
+
+def test_attention_module_gradients_with_and_without_the_forward_zero_fill(monkeypatch):
+    """AttentionFn end to end (LayerNorm -> q|kv -> RoPE -> attention -> to_out): every gradient with the dQ accumulator cleared by the forward kernel
+    against OSUF_ATTN_NO_ZDQ=1 (the memset in the backward entry point), and a no-grad forward allocates no workspace."""
+    from osufusion_amd.modules.unet import Attention
+    torch.manual_seed(3)
+    att = Attention(256, heads=4, dim_head=64, kv_heads=1, context_len=1024).to(DEV)
+    x = torch.randn(2, 1024, 256, device=DEV)
+    res = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("OSUF_ATTN_NO_ZDQ", "1")
+        else:
+            monkeypatch.delenv("OSUF_ATTN_NO_ZDQ", raising=False)
+        for p in att.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_()
+        with forced_compute_dtype(torch.bfloat16):
+            y = att(xi)
+            y.float().square().mean().backward()
+        res[off] = [xi.grad.clone()] + [p.grad.clone() for p in att.parameters()]
+    for a, b in zip(res[False], res[True]):
+        assert torch.isfinite(a).all() and ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item() < 1e-5
+    monkeypatch.delenv("OSUF_ATTN_NO_ZDQ", raising=False)
+    calls = []
+    real = ops.fused_bwd_workspace
+    monkeypatch.setattr(ops, "fused_bwd_workspace", lambda *a, **k: calls.append(1) or real(*a, **k))
+    with torch.no_grad(), forced_compute_dtype(torch.bfloat16):
+        att(x)
+    assert not calls
