@@ -172,6 +172,14 @@ int osuf_mqa_fwd_qs(const void* q, long ldq, const void* k, long ldk, const void
  * pipe with HBM idle, so the fill costs nothing there; in front of the backward sweep it is 66 us per N = 4096 layer.  head_dim 64 only. */
 int osuf_mqa_fwd_zdq(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
                      float* lse2, int B, int H, int N, int head_dim, float scale, int qs, float* zero_dq, hipStream_t stream);
+/* The forward on UN-rotated queries: q_raw = the q block of the q|kv projection as the GEMM left it (bf16).  The kernel rotates each wave's
+ * 32 x 64 query tile (rope_cos / rope_sin: [N][32] fp32), multiplies it by q_mul = scale * log2 e and rounds it to bf16 once -- osuf_rope_cast_qs'
+ * arithmetic -- and stores it to q_out ([B*N][ldqo], may be NULL: inference) for osuf_mqa_bwd_fused_qs.  k / v: already rotated / cast
+ * (osuf_rope_cast on those two head blocks alone: 128 of the (H + 2) * 64 columns).  zero_dq: as osuf_mqa_fwd_zdq, may be NULL.  head_dim 64.
+ * Replaces the q part of `apply_rotary_pos_emb` + the cast in front of SDPA (attention.py:52-58,87-92) -- a full read + write of the q|kv rows. */
+int osuf_mqa_fwd_rope(const void* q_raw, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
+                      float* lse2, int B, int H, int N, int head_dim, float scale, const float* rope_cos, const float* rope_sin,
+                      float q_mul, void* q_out, long ldqo, float* zero_dq, hipStream_t stream);
 /* Attend(q, k, v, attn_mask) (attention.py:77-99): the reference casts the mask to bf16 and passes it to SDPA as an additive bias of
  * the scaled scores (so a bool mask adds 1.0 / 0.0 -- kept).  mask: bf16, element strides over (batch, head, query, key), 0 for a
  * broadcast dimension.  Inference only (no backward entry point); all head dims go through the generic kernel.

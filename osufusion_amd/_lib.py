@@ -47,6 +47,7 @@ SIGNATURES = {
     "osuf_mqa_fwd": [P, L, P, L, P, L, P, L, I, P, I, I, I, I, F, P],
     "osuf_mqa_fwd_qs": [P, L, P, L, P, L, P, L, I, P, I, I, I, I, F, P],
     "osuf_mqa_fwd_zdq": [P, L, P, L, P, L, P, L, I, P, I, I, I, I, F, I, P, P],
+    "osuf_mqa_fwd_rope": [P, L, P, L, P, L, P, L, I, P, I, I, I, I, F, P, P, F, P, L, P, P],
     "osuf_mqa_fwd_masked": [P, L, P, L, P, L, P, L, I, P, P, L, L, L, L, I, I, I, I, F, P],
     "osuf_attn_delta": [P, L, P, L, I, P, I, I, I, I, P],
     "osuf_mqa_bwd_dq": [P, L, P, L, P, L, P, L, P, P, P, L, I, I, I, I, F, I, P, P, I, P],

@@ -120,6 +120,7 @@ struct AttnArgs {
   const float* rcos; const float* rsin;         // [N][32] RoPE tables: when set, dQ / dK are stored as gradients of the UN-rotated q / k
   int B, H, N;
   float scale;
+  bf16_t* qout; long ldqo; float qmul;          // osuf_mqa_fwd_rope: q arrives un-rotated; rotated * qmul it is used here and (qout != null) stored for the backward
   float* zdq;                                   // osuf_mqa_fwd_zdq: the backward's fp32 dQ accumulator [B*N][H*64], zero-filled by the forward kernel (null: not)
   float cexp, kmul;                             // exponent multiplier of S (scale * log2 e; 1 when q arrives pre-scaled by it: the *_qs entry points)
                                                 // and the multiplier of the dK sums (scale; scale / cexp = 1 / log2 e for pre-scaled q)
@@ -214,7 +215,9 @@ struct KVStageInc {
 // QS (queries pre-scaled by scale * log2 e, osuf_mqa_fwd_qs): the scores ARE the exponents, so the running maximum rides the S chain as its C
 // operand (S' = K Qs^T - m_run: 16 registers that change only when a row is rescaled) and p = exp2(S') needs no per-element fma
 // WHOLE (N % 64 == 0): the K / V loads carry no bounds check and there is no masked copy of the tile body
-template <int NW, bool QS = false, bool WHOLE = false>
+// ROPE (osuf_mqa_fwd_rope): the query tile is rotated (rcos / rsin) and multiplied by qmul in the prologue, rounded to bf16 once -- the arithmetic of
+// rope_cast_kernel, which then only has the K | V columns left to do -- and written to qout for the backward when that is given
+template <int NW, bool QS = false, bool WHOLE = false, bool ROPE = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [2][K 8K | V 8K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -232,13 +235,43 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
   // the 16 fragment registers live across the loop pushed the kernel over 128 VGPRs; at <= 128 four waves per SIMD fit
   // (two workgroups per CU): measured 812 -> ~890 TFLOP/s.
   char* qtile = smem + 32768 + wave * 4096;
+  // the first K / V tile is requested BEFORE the query tile is built: behind the ROPE form's rotation (loads -> wait -> arithmetic) its latency
+  // came on top of the queries' (+1.75 us per workgroup, measured)
+  KVStageInc<NW * 64> st;
+  st.init(a, b, tid);
+  st.template load<WHOLE>(a, 0);
   {
     const bf16_t* qp = a.q + ((long)b * a.N + qrow) * a.ldq + h * D;
+    if constexpr (ROPE) {
+      // the lane's chunks ks and ks + 2 hold columns c and c + 32 of the head: the rotation's partners are lane-local
+      u32x4 zq[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+      if (qok) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          float x1[8], x2[8], cs[8], sn[8];
+          load8(qp + 16 * pr + 8 * lh, x1);
+          load8(qp + 32 + 16 * pr + 8 * lh, x2);
+          load8(a.rcos + (long)qrow * 32 + 16 * pr + 8 * lh, cs);
+          load8(a.rsin + (long)qrow * 32 + 16 * pr + 8 * lh, sn);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float a1 = x1[e] * cs[e] - x2[e] * sn[e];
+            const float a2 = x2[e] * cs[e] + x1[e] * sn[e];
+            x1[e] = a1 * a.qmul; x2[e] = a2 * a.qmul;
+          }
+          store8(reinterpret_cast<bf16_t*>(&zq[pr]), x1);
+          store8(reinterpret_cast<bf16_t*>(&zq[pr + 2]), x2);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) *reinterpret_cast<u32x4*>(qtile + tile_off(lr, (2 * ks + lh) * 16)) = zq[ks];
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       u32x4 z = {0u, 0u, 0u, 0u};
       if (qok) z = *reinterpret_cast<const u32x4*>(qp + 16 * ks + 8 * lh);
       *reinterpret_cast<u32x4*>(qtile + tile_off(lr, (2 * ks + lh) * 16)) = z;
+    }
     }
   }
   f32x16 o[2];
@@ -250,9 +283,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
 
   const LaneOffs lo(lane);
   const int ntiles = (a.N + 63) >> 6;
-  KVStageInc<NW * 64> st;
-  st.init(a, b, tid);
-  st.template load<WHOLE>(a, 0);
   st.store(smem, smem + 8192, tid);
   __syncthreads();
   // one 64-key tile; MASK only for a ragged last tile (a branch-free mask on every tile costs 64 VALU ops per tile)
@@ -386,6 +416,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void mqa_fwd_kernel(AttnA
         if (a.o_is_f32) store4(reinterpret_cast<float*>(a.o) + m * a.ldo + h * D + d0, v4);
         else store4(reinterpret_cast<bf16_t*>(a.o) + m * a.ldo + h * D + d0, v4);
       }
+  }
+  // osuf_mqa_fwd_rope: the rotated query tile goes to memory for the backward from its LDS slice HERE, behind the loop -- stored in the prologue, the
+  // stores' completion sat in front of the first barrier (vmcnt counts stores): +1.75 us per workgroup, the whole gain of the fusion
+  if constexpr (ROPE) {
+    if (a.qout != nullptr && qok) {
+      bf16_t* qo = a.qout + ((long)b * a.N + qrow) * a.ldqo + h * D;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        *reinterpret_cast<u32x4*>(qo + 16 * ks + 8 * lh) = *reinterpret_cast<const u32x4*>(qtile + tile_off(lr, (2 * ks + lh) * 16));
+    }
   }
   // osuf_mqa_fwd_zdq: this wave's 32 rows x 256 B of the backward's dQ accumulator are cleared here -- the loop above is bound by the vector pipe with
   // HBM idle (0.16 TB/s), so the 8 stores per wave are free where the hipMemsetAsync in front of the backward sweep cost 66 us per N = 4096 layer
@@ -1904,8 +1944,9 @@ static inline int ew_grid(long total_threads) {
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // head dims served by the generic kernels of attn_generic.hpp (64 has the tuned kernels of this file): padded tile width, 0 = unsupported
 static int gen_dp(int head_dim) { return head_dim == 16 || head_dim == 32 ? 32 : head_dim == 128 ? 128 : 0; }
+struct FwdRope { const float* cos; const float* sin; float qmul; void* qout; long ldqo; };   // osuf_mqa_fwd_rope's extra operands
 static int mqa_fwd_impl(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
-                        float* lse2, int B, int H, int N, int head_dim, float scale, bool qs, hipStream_t stream, float* zdq);
+                        float* lse2, int B, int H, int N, int head_dim, float scale, bool qs, hipStream_t stream, float* zdq, const FwdRope* rope = nullptr);
 extern "C" int osuf_mqa_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
                             float* lse2, int B, int H, int N, int head_dim, float scale, hipStream_t stream) {
   return mqa_fwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, o_dtype, lse2, B, H, N, head_dim, scale, false, stream, nullptr);
@@ -1923,16 +1964,29 @@ extern "C" int osuf_mqa_fwd_zdq(const void* q, long ldq, const void* k, long ldk
   if (head_dim != D || !zero_dq) return OSUF_EUNSUPPORTED;
   return mqa_fwd_impl(q, ldq, k, ldk, v, ldv, o, ldo, o_dtype, lse2, B, H, N, head_dim, scale, qs != 0, stream, zero_dq);
 }
+// The forward on UN-rotated queries: q_raw is the q block of the q|kv projection as the GEMM left it (bf16); the kernel rotates each wave's 32 x 64 query
+// tile (rope_cos / rope_sin, [N][32] fp32), multiplies it by q_mul = scale * log2 e and rounds it to bf16 once -- exactly osuf_rope_cast_qs' arithmetic
+// -- before the tile loop, and stores it to q_out (may be NULL: inference) for the backward.  k / v: rotated / cast by osuf_rope_cast on their two
+// head blocks alone.  zero_dq as osuf_mqa_fwd_zdq (may be NULL).  head_dim 64.
+extern "C" int osuf_mqa_fwd_rope(const void* q_raw, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
+                                 float* lse2, int B, int H, int N, int head_dim, float scale, const float* rope_cos, const float* rope_sin,
+                                 float q_mul, void* q_out, long ldqo, float* zero_dq, hipStream_t stream) {
+  if (head_dim != D) return OSUF_EUNSUPPORTED;
+  const FwdRope r = {rope_cos, rope_sin, q_mul, q_out, ldqo};
+  return mqa_fwd_impl(q_raw, ldq, k, ldk, v, ldv, o, ldo, o_dtype, lse2, B, H, N, head_dim, scale, true, stream, zero_dq, &r);
+}
 static int mqa_fwd_impl(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o, long ldo, int o_dtype,
-                        float* lse2, int B, int H, int N, int head_dim, float scale, bool qs, hipStream_t stream, float* zdq) {
+                        float* lse2, int B, int H, int N, int head_dim, float scale, bool qs, hipStream_t stream, float* zdq, const FwdRope* rope) {
   if (head_dim != D && !gen_dp(head_dim)) return OSUF_EUNSUPPORTED;
   if (zdq && (head_dim != D || !al16(zdq))) return OSUF_EINVAL;
+  if (rope && (head_dim != D || !qs || !rope->cos || !rope->sin || !(rope->qmul > 0.f) || (rope->qout && (rope->ldqo % 8 || !al16(rope->qout))))) return OSUF_EINVAL;
   if (B <= 0 || H <= 0 || N <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || !al16(q) || !al16(k) || !al16(v) || !al16(o)) return OSUF_EINVAL;
   AttnArgs a = {};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
   a.o = o; a.ldo = ldo; a.o_is_f32 = o_dtype == OSUF_DT_F32; a.lse2 = lse2; a.B = B; a.H = H; a.N = N; a.scale = scale; a.cexp = scale * kLog2e; a.kmul = scale;
   if (qs) a.cexp = 1.f;
   a.zdq = zdq;
+  if (rope) { a.rcos = rope->cos; a.rsin = rope->sin; a.qmul = rope->qmul; a.qout = (bf16_t*)rope->qout; a.ldqo = rope->ldqo; }
   const int nvb = ((N + 31) / 32) * H;
   if (head_dim != D) {
     const dim3 grid((nvb + 3) / 4, B);
@@ -1943,7 +1997,10 @@ static int mqa_fwd_impl(const void* q, long ldq, const void* k, long ldk, const 
   const bool whole = (N & 63) == 0 && getenv("OSUF_ATTN_FWD_NOWHOLE") == nullptr;
   const dim3 grid((nvb + 7) / 8, B);
   const int lds = 32768 + 8 * 4096;
-  if (qs && getenv("OSUF_ATTN_FWD_NOQSK") == nullptr) {
+  if (rope) {
+    if (whole) hipLaunchKernelGGL((mqa_fwd_kernel<8, true, true, true>), grid, dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL((mqa_fwd_kernel<8, true, false, true>), grid, dim3(512), lds, stream, a);
+  } else if (qs && getenv("OSUF_ATTN_FWD_NOQSK") == nullptr) {
     if (whole) hipLaunchKernelGGL((mqa_fwd_kernel<8, true, true>), grid, dim3(512), lds, stream, a);
     else hipLaunchKernelGGL((mqa_fwd_kernel<8, true>), grid, dim3(512), lds, stream, a);
   } else if (whole) hipLaunchKernelGGL((mqa_fwd_kernel<8, false, true>), grid, dim3(512), lds, stream, a);

@@ -905,12 +905,19 @@ class AttentionFn(torch.autograd.Function):
         # the softmax scale (x log2 e) rides the queries' one bf16 rounding where the kernels have the pre-scaled form: the attention backward's
         # generated loop then takes Qs K^T - lse2 straight as the exponent (64 fewer vector instructions per (head, query block) pair)
         qs = ops.q_prescale_ok(D, ops.ATTN_BWD_DEFAULT)
-        qkv_r = ops.rope_cast(qkv, cos, sin, N, H + G, H + 2 * G, D, q_mul=scale * ops.LOG2E if qs else 1.0, n_q_heads=H)   # rotate q and k heads; cast v
-        del qkv
         # a backward will follow: the forward kernel zero-fills the dQ accumulator of this layer's fused backward sweep (private workspace, kept to then)
         # (grad_mode: the caller's torch.is_grad_enabled() -- needs_input_grad alone is also true under no_grad, e.g. in the sampler)
-        dq_ws = ops.fused_bwd_workspace(B, N, H, D, dt, x.device) if (G == 1 and grad_mode and any(ctx.needs_input_grad)) else None
-        o, lse = ops.mqa_fwd(qkv_r, B, N, H, D, dt, scale, kv_heads=G, qs=qs, zero_dq=dq_ws)
+        will_bwd = grad_mode and any(ctx.needs_input_grad)
+        dq_ws = ops.fused_bwd_workspace(B, N, H, D, dt, x.device) if (G == 1 and will_bwd) else None
+        # (with the stored queries AND the zero fill behind its loop the kernel's tail grows by ~30-50 us whatever N is: measured against the 15 us a
+        #  RoPE pass over N = 1024 rows saves, the training forward of short sequences keeps the separate pass -- tools/time_fwd_rope.py)
+        if ops.fwd_rope_ok(qkv, D, G, qs) and (N >= 2048 or not will_bwd):
+            # the attention kernel rotates / scales / rounds its own query tiles (and stores them for the backward): only K | V take the RoPE + cast pass
+            qkv_r, o, lse = ops.mqa_fwd_rope(qkv, cos, sin, B, N, H, D, dt, scale, write_q=will_bwd, zero_dq=dq_ws)
+        else:
+            qkv_r = ops.rope_cast(qkv, cos, sin, N, H + G, H + 2 * G, D, q_mul=scale * ops.LOG2E if qs else 1.0, n_q_heads=H)   # rotate q and k heads; cast v
+            o, lse = ops.mqa_fwd(qkv_r, B, N, H, D, dt, scale, kv_heads=G, qs=qs, zero_dq=dq_ws)
+        del qkv
         ctx.dq_ws = dq_ws
         wpo = cache.packs(("po", dt), (wo,) if base is None else (base[1],), wo, "same", dt)[0]
         out = ops.gemm_nt(o, wpo, bo, residual=xn, out_shape=x.shape)

@@ -168,7 +168,7 @@ def zeros(shape, dtype: torch.dtype, device) -> torch.Tensor:
     return torch.zeros(shape, dtype=dtype, device=device)
 
 
-_TIMED_AS = {"osuf_mqa_fwd_qs": "osuf_mqa_fwd", "osuf_mqa_fwd_zdq": "osuf_mqa_fwd", "osuf_mqa_bwd_fused_qs": "osuf_mqa_bwd_fused"}    # pre-scaled-query forms: timed under the plain name
+_TIMED_AS = {"osuf_mqa_fwd_qs": "osuf_mqa_fwd", "osuf_mqa_fwd_zdq": "osuf_mqa_fwd", "osuf_mqa_fwd_rope": "osuf_mqa_fwd", "osuf_mqa_bwd_fused_qs": "osuf_mqa_bwd_fused"}    # pre-scaled-query forms: timed under the plain name
 
 
 def call(name: str, *args, meta=None) -> None:
@@ -498,6 +498,29 @@ def mqa_fwd(qkv: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.
         call("osuf_mqa_fwd_qs" if qs else "osuf_mqa_fwd", base + 2 * g * r * D, ld, base + 2 * (H + g) * D, ld, base + 2 * (H + G + g) * D, ld, o.data_ptr() + eo * g * r * D,
              H * D, _DT[out_dtype], lse.data_ptr() + 4 * g * B * r * N, B, r, N, D, scale, _stream(), meta=LaunchSize(N, B))
     return o, lse
+
+
+def fwd_rope_ok(qkv: torch.Tensor, head_dim: int, kv_heads: int, qs: bool) -> bool:
+    """The forward that rotates its own queries (mqa_fwd_rope) applies: bf16 projections, 64-wide heads, one K/V head, pre-scaled-query kernels."""
+    return qs and head_dim == 64 and kv_heads == 1 and qkv.dtype == torch.bfloat16 and os.environ.get("OSUF_ATTN_NO_FWD_ROPE") != "1"
+
+
+def mqa_fwd_rope(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.dtype, scale: float,
+                 write_q: bool = True, zero_dq: Optional[torch.Tensor] = None):
+    """RoPE + attention forward from the raw bf16 q|kv projections [B*N][(H+2)*D]: K is rotated and V copied by a rope_cast over THEIR two head blocks
+    (128 of the (H + 2) * 64 columns); the queries are rotated, multiplied by scale * log2 e and rounded once inside the attention kernel, which
+    stores them for the backward when write_q (else the q columns of the returned rows stay unwritten: inference).  Returns (qkv_r, o, lse2)."""
+    M, W, ld = _rows(qkv)
+    assert qkv.dtype == torch.bfloat16 and D == 64 and W == (H + 2) * D
+    qkv_r = torch.empty(qkv.shape, dtype=torch.bfloat16, device=qkv.device)
+    kv_in, kv_out = qkv.data_ptr() + 2 * H * D, qkv_r.data_ptr() + 2 * H * D
+    call("osuf_rope_cast", _DT[torch.bfloat16], kv_in, ld, kv_out, W, _p(cos), _p(sin), M, N, 1, 2, D, _stream())     # k: rotate; v: copy
+    o = torch.empty((B, N, H * D), dtype=out_dtype, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    assert zero_dq is None or (zero_dq.dtype == torch.float32 and zero_dq.numel() >= B * N * H * D)
+    call("osuf_mqa_fwd_rope", qkv.data_ptr(), ld, kv_out, W, kv_out + 2 * D, W, o.data_ptr(), H * D, _DT[out_dtype], lse.data_ptr(), B, H, N, D, scale,
+         _p(cos), _p(sin), scale * LOG2E, qkv_r.data_ptr() if write_q else None, W, _p(zero_dq), _stream(), meta=LaunchSize(N, B))
+    return qkv_r, o, lse
 
 
 def mqa_fwd_masked(qkv: torch.Tensor, mask4: torch.Tensor, B: int, N: int, H: int, D: int, out_dtype: torch.dtype, scale: float) -> torch.Tensor:

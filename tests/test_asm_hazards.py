@@ -47,7 +47,9 @@ def test_asm_mfma_kernels_have_no_unpadded_hazards(tmp_path):
     # the generated backward loop runs at one wave per SIMD on the whole register file, also without scratch traffic in its loop
     import re
     text = asm.read_text()
-    for sym, max_scratch in [(f"_Z14mqa_fwd_kernelILi8ELb{qs}ELb{whole}EEv8AttnArgs", 0) for qs in (0, 1) for whole in (0, 1)]:
-        m = re.search(re.escape(sym) + r":.*?; NumVgprs: (\d+).*?; ScratchSize: (\d+)", text, re.S)
-        assert m, sym
+    found = re.findall(r"^(_Z14mqa_fwd_kernelILi8E\w+):.*?; NumVgprs: (\d+).*?; ScratchSize: (\d+)", text, re.S | re.M)
+    assert len(found) >= 6, [f[0] for f in found]            # QS x WHOLE, + the two ROPE forms
+    for sym, nv, sc in found:
+        m = re.match(r"(\d+) (\d+)", f"{nv} {sc}")
+        max_scratch = 0
         assert int(m.group(1)) <= 128 and int(m.group(2)) <= max_scratch, (sym, m.group(1), m.group(2))

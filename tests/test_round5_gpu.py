@@ -245,3 +245,66 @@ def test_attention_module_gradients_with_and_without_the_forward_zero_fill(monke
     with torch.no_grad(), forced_compute_dtype(torch.bfloat16):
         att(x)
     assert not calls
+
+
+@pytest.mark.parametrize("Bn,N,H", [(2, 200, 3), (1, 512, 2), (2, 1024, 4), (1, 2048, 16)])
+def test_forward_rotates_its_own_queries(Bn, N, H):
+    """osuf_mqa_fwd_rope: the attention kernel rotates, scales and rounds its query tiles itself (attention.py:52-58,87-92: RoPE, then the bf16 cast in
+    front of SDPA) and stores them for the backward; only the K | V head blocks take the stand-alone RoPE + cast pass.  Against osuf_rope_cast_qs +
+    osuf_mqa_fwd_qs on the same raw projections: K / V columns bit-equal (same kernel), the stored queries equal to at most one bf16 step (two ulps of the smaller neighbour at a binade edge) (the two
+    kernels' fp32 expressions may contract differently), output and log-sum-exp equal to bf16 / fp32 noise -- bit-equal when the queries are;
+    without q_out (inference) the same output."""
+    D = 64
+    scale = D ** -0.5
+    raw = torch.randn(Bn, N, (H + 2) * D, device=DEV).to(torch.bfloat16)
+    cos, sin = Fn.rope_tables(N, D, 2 * N, DEV)
+    ref = ops.rope_cast(raw, cos, sin, N, H + 1, H + 2, D, q_mul=scale * ops.LOG2E, n_q_heads=H)
+    o0, lse0 = ops.mqa_fwd(ref, Bn, N, H, D, torch.bfloat16, scale, qs=True)
+    assert ops.fwd_rope_ok(raw, D, 1, True)
+    qkv_r, o1, lse1 = ops.mqa_fwd_rope(raw, cos, sin, Bn, N, H, D, torch.bfloat16, scale, write_q=True)
+    assert torch.equal(qkv_r[..., H * D:], ref[..., H * D:])
+    q0, q1 = ref[..., : H * D].float(), qkv_r[..., : H * D].float()
+    same = (q0 == q1).float().mean().item()
+    ulp = (q0.abs().clamp_min(1e-30).log2().floor() - 7).exp2()
+    tiny = q0.abs().amax() * 2.0 ** -16                    # a cancelling x1 cos - x2 sin: the two contractions differ by fp32 noise of the PRODUCTS
+    assert ((q0 - q1).abs() <= torch.maximum(2 * ulp, tiny)).all() and same > 0.99, same
+    report(f"fwd_rope/B{Bn}_N{N}_H{H}", q_bit_equal_share=same)
+    if same == 1.0:
+        assert torch.equal(o0, o1) and torch.equal(lse0, lse1)
+    else:
+        assert ((o0.float() - o1.float()).norm() / o0.float().norm()).item() < 2e-3 and (lse0 - lse1).abs().max().item() < 2e-2
+    _, o2, lse2 = ops.mqa_fwd_rope(raw, cos, sin, Bn, N, H, D, torch.bfloat16, scale, write_q=False)
+    assert torch.equal(o1, o2) and torch.equal(lse1, lse2)
+    # with the dQ accumulator's zero fill riding along
+    ws = ops.fused_bwd_workspace(Bn, N, H, D, torch.float32, DEV, variant=ops.ATTN_FUSED)
+    ws.fill_(float("nan"))
+    _, o3, lse3 = ops.mqa_fwd_rope(raw, cos, sin, Bn, N, H, D, torch.bfloat16, scale, write_q=True, zero_dq=ws)
+    assert torch.equal(o1, o3) and int((ws[: Bn * N * H * D] != 0).sum().item()) == 0
+
+
+def test_attention_module_with_and_without_the_rotating_forward(monkeypatch):
+    """AttentionFn end to end, default path (the forward rotates its queries) against OSUF_ATTN_NO_FWD_ROPE=1 (rope_cast over all heads): output and every
+    gradient to bf16 rounding noise; and the inference forward (no_grad: no stored queries) equals the training forward."""
+    from osufusion_amd.modules.unet import Attention
+    torch.manual_seed(5)
+    att = Attention(256, heads=4, dim_head=64, kv_heads=1, context_len=2048).to(DEV)
+    x = torch.randn(1, 2048, 256, device=DEV)                  # (N >= 2048: where the training forward takes the rotating kernel)
+    res = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("OSUF_ATTN_NO_FWD_ROPE", "1")
+        else:
+            monkeypatch.delenv("OSUF_ATTN_NO_FWD_ROPE", raising=False)
+        for p in att.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_()
+        with forced_compute_dtype(torch.bfloat16):
+            y = att(xi)
+            y.float().square().mean().backward()
+        res[off] = [y.detach().float(), xi.grad.clone()] + [p.grad.clone() for p in att.parameters()]
+    for a, b in zip(res[False], res[True]):
+        assert torch.isfinite(a).all() and ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item() < 2e-3
+    monkeypatch.delenv("OSUF_ATTN_NO_FWD_ROPE", raising=False)
+    with torch.no_grad(), forced_compute_dtype(torch.bfloat16):
+        y_inf = att(x)
+    assert torch.equal(y_inf.float(), res[False][0])
