@@ -130,6 +130,12 @@ int osuf_ln_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, v
  *      (modules/residual.py:29-32,135-137) ------------------------------------------------------------------ */
 int osuf_rowdot(int dtype, const void* h, long ldh, const float* w, long w_stride, const float* bias, float* out,
                 int M, int C, int L, hipStream_t stream);
+/* GlobalContext pooling (residual.py:29-31) in ONE pass over h: p[B*L] = softmax_n(h . wk + bk) and pooled[B][C] = sum_n p[n] h[b,n,:] (fp32), by a
+ * running softmax per workgroup + a second stage that adds the workgroups' partials in order (`part`: osuf_gca_pool_workspace_bytes bytes of
+ * scratch).  Replaces osuf_rowdot + osuf_softmax_rows + osuf_wcolsum (two reads of h) on that path; no atomics: bit-reproducible. */
+long osuf_gca_pool_workspace_bytes(int M, int C, int L);
+int osuf_gca_pool(int dtype, const void* h, long ldh, const float* wk, const float* bk, float* part, float* p, float* pooled,
+                  int M, int C, int L, hipStream_t stream);
 int osuf_softmax_rows(float* p, int B, int L, hipStream_t stream);
 /* osuf_wcolsum: out[b][c] (+)= sum_l w[b][l] * a[b][l][c] (* bmul[b][l][c]).  partial == NULL: row chunks meet by fp32 atomics in a
  * zero-initialised `out`; partial = B * ceil(L / 64) * C floats: chunk sums are stored and added in chunk order (`out` overwritten,

@@ -35,6 +35,8 @@ SIGNATURES = {
     "osuf_softmax_rows": [P, I, I, P],
     "osuf_wcolsum": [I, P, L, P, L, P, P, I, I, I, P, P],
     "osuf_gn_stats": [I, P, L, P, P, I, I, I, P],
+    "osuf_gca_pool": [I, P, L, P, P, P, P, P, I, I, I, P],
+    "osuf_gca_pool_workspace_bytes": [I, I, I],
     "osuf_gn_stats_parts": [I, P, L, P, I, I, I, P],
     "osuf_gn_apply_fwd_parts": [I, P, L, P, L, P, P, P, P, P, I, I, I, P],
     "osuf_gn_stats_workspace_bytes": [I, I, I],

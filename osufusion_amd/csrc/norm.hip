@@ -497,6 +497,135 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const T* h, long ldh, const
   }
 }
 
+// GlobalContext pooling in ONE pass over h (round 5; residual.py:29-31: logits = to_k(h), softmax over the sequence, pooled = sum_n p[n] h[n]):
+// the row's logit, a running softmax (per lane: running maximum m, sum l, the lane's weighted column sums relative to m) and the block's partial
+// (acc[C], m, l) in part[b][blk][C + 2]; the raw logits are kept in logit[B*L] for the second stage's probabilities.  No atomics: the second
+// stage adds the blocks in order, so the result is bit-reproducible (what the sampler needs) -- and h is read ONCE where rowdot + wcolsum read it twice.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void gca_pool_kernel(const T* h, long ldh, const float* wk, const float* bk, float* part, float* logit, int C, int L,
+                                                       int G, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);                 // [4 waves][C + 2]
+  const int chunks = C >> 3;
+  const int rows_per_wave = 64 / G;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = lane % G, gr = lane / G;
+  const int b = blockIdx.y;
+  const int n_begin = blockIdx.x * rows_per_block, n_end = min(L, n_begin + rows_per_block);
+  const float bv = bk ? bk[0] : 0.f;
+  float w[NCH][8], acc[NCH][8];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int ch = gl + j * G;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { w[j][e] = 0.f; acc[j][e] = 0.f; }
+    if (ch < chunks) load8(wk + ch * 8, w[j]);
+  }
+  float m = -INFINITY, l = 0.f;
+  for (int n0 = n_begin + wave * rows_per_wave; n0 < n_end; n0 += 4 * rows_per_wave) {
+    const int n = n0 + gr;
+    const bool rok = n < n_end;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int ch = gl + j * G;
+      if (rok && ch < chunks) {
+        load8(h + ((long)b * L + n) * ldh + ch * 8, v[j]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[j][e] * w[j][e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+      }
+    }
+    s = group_sum_dyn(s, G) + bv;                             // every lane of the row's group holds the logit
+    if (rok) {
+      if (gl == 0) logit[(long)b * L + n] = s;
+      const float mn = fmaxf(m, s);
+      const float alpha = __expf(m - mn), pr = __expf(s - mn);   // first row: m = -inf, alpha = 0
+      l = l * alpha + pr;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = acc[j][e] * alpha + pr * v[j][e];
+      m = mn;
+    }
+  }
+  // the row groups of a wave (same gl, other gr): bring them to a common maximum and add
+  for (int o = G; o < 64; o <<= 1) {
+    const float mo = __shfl_xor(m, o, 64), lo_ = __shfl_xor(l, o, 64);
+    const float M = fmaxf(m, mo);
+    const float fa = m == -INFINITY ? 0.f : __expf(m - M), fb = mo == -INFINITY ? 0.f : __expf(mo - M);
+    l = l * fa + lo_ * fb;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float ao = __shfl_xor(acc[j][e], o, 64); acc[j][e] = acc[j][e] * fa + ao * fb; }
+    m = M;
+  }
+  // the four waves through LDS, in wave order
+  if (gr == 0) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int ch = gl + j * G;
+      if (ch < chunks) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave * (C + 2) + ch * 8 + e] = acc[j][e];
+      }
+    }
+    if (gl == 0) { red[wave * (C + 2) + C] = m; red[wave * (C + 2) + C + 1] = l; }
+  }
+  __syncthreads();
+  float mw[4], f[4];
+  float M = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { mw[k] = red[k * (C + 2) + C]; M = fmaxf(M, mw[k]); }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) f[k] = mw[k] == -INFINITY ? 0.f : __expf(mw[k] - M);
+  float* dst = part + ((long)b * gridDim.x + blockIdx.x) * (C + 2);
+  for (int i = threadIdx.x; i < C; i += 256)
+    dst[i] = ((red[i] * f[0] + red[(C + 2) + i] * f[1]) + red[2 * (C + 2) + i] * f[2]) + red[3 * (C + 2) + i] * f[3];
+  if (threadIdx.x == 0) {
+    dst[C] = M;
+    dst[C + 1] = ((red[C + 1] * f[0] + red[(C + 2) + C + 1] * f[1]) + red[2 * (C + 2) + C + 1] * f[2]) + red[3 * (C + 2) + C + 1] * f[3];
+  }
+}
+
+// second stage, one workgroup per sample: the blocks' partials in block order -> pooled[b][C]; the probabilities p[b][n] = exp(logit - M) / Z in place
+// of the logits (the backward's operand)
+__global__ __launch_bounds__(256) void gca_pool_finish_kernel(const float* part, float* logit_p, float* pooled, int C, int L, int nblk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* fb = reinterpret_cast<float*>(smem);                  // [nblk] block factors exp(m_blk - M)
+  __shared__ float redm[4], redz[4];
+  const int b = blockIdx.x;
+  const float* pb = part + (long)b * nblk * (C + 2);
+  float mx = -INFINITY;
+  for (int k = threadIdx.x; k < nblk; k += 256) mx = fmaxf(mx, pb[(long)k * (C + 2) + C]);
+  mx = group_max<64>(mx);
+  if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  const float M = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+  for (int k = threadIdx.x; k < nblk; k += 256) fb[k] = __expf(pb[(long)k * (C + 2) + C] - M);
+  __syncthreads();
+  // Z: four threads add a quarter of the blocks each, in block order, then the four sums in order: a fixed order for any nblk
+  float z = 0.f;
+  if (threadIdx.x < 4) {
+    const int per = (nblk + 3) / 4;
+    for (int k = threadIdx.x * per; k < min(nblk, (threadIdx.x + 1) * per); ++k) z += pb[(long)k * (C + 2) + C + 1] * fb[k];
+    redz[threadIdx.x] = z;
+  }
+  __syncthreads();
+  const float Z = ((redz[0] + redz[1]) + redz[2]) + redz[3];
+  const float inv = 1.f / Z;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f;
+    for (int k = 0; k < nblk; ++k) a += pb[(long)k * (C + 2) + c] * fb[k];
+    pooled[(long)b * C + c] = a * inv;
+  }
+  float* row = logit_p + (long)b * L;
+  for (int n = threadIdx.x; n < L; n += 256) row[n] = __expf(row[n] - M) * inv;
+}
+
 // in-place softmax over the L logits of each sample (one workgroup per sample)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* p, int L) {
   float* row = p + (long)blockIdx.x * L;
@@ -871,6 +1000,36 @@ extern "C" int osuf_rowdot(int dtype, const void* h, long ldh, const float* w, l
   const int G = pick_group(C / 8);
   DISPATCH_T(dtype, hipLaunchKernelGGL(rowdot_kernel<T>, dim3(row_grid(M, G)), dim3(256), 0, stream, (const T*)h, ldh, w, w_stride,
                                        bias, out, M, C, L, G));
+  return osuf_launch_status();
+}
+
+// rows per workgroup: ~1,024 workgroups over the batch, 32 ... 128 rows each (tools/bench_gca.py, B = 32: L = 4096 / 8192 best at 128, 2048 at 64, <= 1024 at 32;
+// more rows amortise the end-of-block reduction, fewer keep the chip full); OSUF_GCA_RPB overrides (A/B)
+static int gca_pool_rows_per_block(int M) {
+  const char* e = getenv("OSUF_GCA_RPB");
+  if (e) return atoi(e) > 0 ? atoi(e) : 64;
+  int r = 32;
+  while (r < 128 && (long)M / (2 * r) >= 1024) r <<= 1;
+  return r;
+}
+extern "C" long osuf_gca_pool_workspace_bytes(int M, int C, int L) {
+  if (M <= 0 || L <= 0 || M % L || C <= 0 || C % 8 || C > 2048) return 0;
+  const int rpb = 32;                                    // the smallest block the launch may pick: an upper bound
+  return (long)(M / L) * ((L + rpb - 1) / rpb) * (C + 2) * (long)sizeof(float);
+}
+/* GlobalContext pooling in one pass over h: p[B*L] receives softmax_n(h . wk + bk), pooled[B][C] = sum_n p[n] h[n]; `part` =
+ * osuf_gca_pool_workspace_bytes(M, C, L) bytes of scratch.  Fixed summation order (bit-reproducible). */
+extern "C" int osuf_gca_pool(int dtype, const void* h, long ldh, const float* wk, const float* bk, float* part, float* p, float* pooled,
+                             int M, int C, int L, hipStream_t stream) {
+  if (bad_c(C) || M <= 0 || L <= 0 || M % L || ldh % 8 || !part || !p || !pooled || !wk) return OSUF_EINVAL;
+  const int B = M / L, G = pick_group(C / 8), nch = (C / 8 + G - 1) / G;
+  const int rpb = std::max(32, gca_pool_rows_per_block(M)), nblk = (L + rpb - 1) / rpb;
+  const size_t lds = (size_t)4 * (C + 2) * sizeof(float);
+  if ((size_t)nblk * sizeof(float) > 60000) return OSUF_EUNSUPPORTED;
+#define GCA_POOL_LAUNCH(NCH_) hipLaunchKernelGGL((gca_pool_kernel<T, NCH_>), dim3(nblk, B), dim3(256), lds, stream, (const T*)h, ldh, wk, bk, part, p, C, L, G, rpb)
+  DISPATCH_T(dtype, if (nch == 1) GCA_POOL_LAUNCH(1); else if (nch == 2) GCA_POOL_LAUNCH(2); else GCA_POOL_LAUNCH(4));
+#undef GCA_POOL_LAUNCH
+  hipLaunchKernelGGL(gca_pool_finish_kernel, dim3(B), dim3(256), (size_t)nblk * sizeof(float), stream, part, p, pooled, C, L, nblk);
   return osuf_launch_status();
 }
 

@@ -709,9 +709,12 @@ class GCAPoolFn(torch.autograd.Function):
     def forward(ctx, h, wk, bk, link=None):
         B, L, C = h.shape
         wkv = wk.reshape(-1).contiguous()
-        p = ops.rowdot(h, wkv, bk.reshape(-1), L)
-        ops.softmax_rows_(p, B, L)
-        pooled = ops.wcolsum(h, None, p, B, L)
+        if ops.gca_pool_fused_ok():                        # one pass over h: logits, running softmax, weighted column sums (round 5)
+            pooled, p = ops.gca_pool(h, wkv, bk.reshape(-1), L)
+        else:
+            p = ops.rowdot(h, wkv, bk.reshape(-1), L)
+            ops.softmax_rows_(p, B, L)
+            pooled = ops.wcolsum(h, None, p, B, L)
         ctx.save_for_backward(h, wkv, p, pooled)
         ctx.wshape, ctx.link = wk.shape, link
         ctx.wk_ref, ctx.bk_ref = wk, bk                   # the Parameters themselves (direct .grad accumulation)

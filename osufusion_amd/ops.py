@@ -384,6 +384,23 @@ def rowdot(h: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], L: in
     return out
 
 
+def gca_pool_fused_ok() -> bool:
+    return os.environ.get("OSUF_GCA_NO_FUSED_POOL") != "1"
+
+
+def gca_pool(h: torch.Tensor, wk: torch.Tensor, bk: Optional[torch.Tensor], L: int):
+    """GlobalContext pooling in one pass over h: returns (pooled (B, C) fp32, p (B*L,) fp32 = softmax over each sample's L logits h . wk + bk).
+    A running softmax per workgroup, the workgroups' partials added in order by a second kernel: no atomics (bit-reproducible)."""
+    M, C, ld = _rows(h)
+    B = M // L
+    need = _lib.load().osuf_gca_pool_workspace_bytes(M, C, L)
+    part = torch.empty(max(need // 4, 1), dtype=torch.float32, device=h.device)
+    p = torch.empty(M, dtype=torch.float32, device=h.device)
+    pooled = torch.empty((B, C), dtype=torch.float32, device=h.device)
+    call("osuf_gca_pool", dt_of(h), _p(h), ld, _p(wk), _p(bk), _p(part), _p(p), _p(pooled), M, C, L, _stream())
+    return pooled, p
+
+
 def softmax_rows_(p: torch.Tensor, B: int, L: int) -> torch.Tensor:
     call("osuf_softmax_rows", _p(p), B, L, _stream())
     return p

@@ -308,3 +308,27 @@ def test_attention_module_with_and_without_the_rotating_forward(monkeypatch):
     with torch.no_grad(), forced_compute_dtype(torch.bfloat16):
         y_inf = att(x)
     assert torch.equal(y_inf.float(), res[False][0])
+
+
+@pytest.mark.parametrize("Bn,L,C", [(3, 520, 96), (2, 1024, 256), (2, 512, 768), (1, 2048, 1024), (2, 64, 2048), (2, 4096, 256)])
+def test_global_context_pooling_in_one_pass(Bn, L, C):
+    """osuf_gca_pool (residual.py:29-31: softmax over the sequence of to_k(h), pooled = sum_n p[n] h[n]) against the three-kernel form it replaces
+    (osuf_rowdot + osuf_softmax_rows + osuf_wcolsum) and against torch in fp64: probabilities and pooled vector to fp32 noise, identical bits on
+    every call (no atomics), ragged L, every channel-chunk geometry (C = 96 ... 2048), logits with a large spread."""
+    for dt in (torch.float32, torch.bfloat16):
+        h = (torch.randn(Bn, L, C, device=DEV) * 2).to(dt)
+        wk = torch.randn(C, device=DEV) * (6.0 / C ** 0.5)          # logits of a few units: a peaked softmax
+        bk = torch.randn(1, device=DEV)
+        pooled, p = ops.gca_pool(h.reshape(Bn * L, C), wk, bk, L)
+        pooled2, p2 = ops.gca_pool(h.reshape(Bn * L, C), wk, bk, L)
+        assert torch.equal(pooled, pooled2) and torch.equal(p, p2)
+        logits = (h.double() @ wk.double()) + bk.double()
+        pref = logits.softmax(-1)
+        want = (pref.unsqueeze(-1) * h.double()).sum(1)
+        assert relmax(p.view(Bn, L), pref.float()) < 1e-4 and relmax(pooled, want.float()) < 1e-4
+        assert torch.allclose(p.view(Bn, L).sum(-1), torch.ones(Bn, device=DEV), atol=1e-5)
+        with ops.reproducible_mode(True):
+            p_old = ops.rowdot(h.reshape(Bn * L, C), wk, bk, L)
+            ops.softmax_rows_(p_old, Bn, L)
+            pooled_old = ops.wcolsum(h.reshape(Bn * L, C), None, p_old, Bn, L)
+        assert relmax(p, p_old) < 1e-4 and relmax(pooled, pooled_old) < 1e-4
