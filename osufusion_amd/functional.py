@@ -920,6 +920,12 @@ class AttentionFn(torch.autograd.Function):
         else:
             qkv_r = ops.rope_cast(qkv, cos, sin, N, H + G, H + 2 * G, D, q_mul=scale * ops.LOG2E if qs else 1.0, n_q_heads=H)   # rotate q and k heads; cast v
             o, lse = ops.mqa_fwd(qkv_r, B, N, H, D, dt, scale, kv_heads=G, qs=qs, zero_dq=dq_ws)
+        # DoRA adapters on to_q / to_kv: their magnitude gradient needs sum_m dy * y over the PRE-RoPE projections.  Kept from here (604 MB per N = 4096
+        # layer at B = 64: 23 GB over the UNet, affordable on 288 GB) instead of running the q|kv GEMM a second time in the backward (39 GEMMs of
+        # ~260 us per DoRA step); OSUF_ATTN_RECOMPUTE_QKV=1 restores the recompute
+        keep_raw = will_bwd and ((aq is not None and aq.m is not None) or (akv is not None and akv.m is not None)) and \
+            os.environ.get("OSUF_ATTN_RECOMPUTE_QKV") != "1"
+        ctx.qkv_raw = qkv if keep_raw else None
         del qkv
         ctx.dq_ws = dq_ws
         wpo = cache.packs(("po", dt), (wo,) if base is None else (base[1],), wo, "same", dt)[0]
@@ -978,7 +984,10 @@ class AttentionFn(torch.autograd.Function):
         packs = AttentionFn._qkv_packs(cache, dt, wq, wkv, aq, akv, ctx.base)
         gq = gkv = (None, None, None)
         if (aq is not None and any(need[13:16])) or (akv is not None and any(need[16:19])):
-            qkv = ops.gemm_nt(xn, packs[0], None, out_shape=(B, N, (H + 2 * G) * D))  # pre-RoPE projections again (for d magnitude)
+            qkv = ctx.qkv_raw                                                     # pre-RoPE projections (for d magnitude): kept by the forward, or again
+            if qkv is None:
+                qkv = ops.gemm_nt(xn, packs[0], None, out_shape=(B, N, (H + 2 * G) * D))
+            ctx.qkv_raw = None
             if aq is not None:
                 gq = adapter_grads(aq, dqkv[..., : H * D], xn, qkv[..., : H * D], None, "same", cache)
             if akv is not None:
