@@ -456,7 +456,7 @@ def main() -> None:
             out["dtype"] = args.timed_mode
         if world == 1 and not args.no_fp32_mode and not args.lora and full and args.timed_mode == "bf16":
             # the compute mode in which north_star's 1e-3 bound holds (exact-f32 MFMA everywhere, bf16 only where the reference casts):
-            # one warm-up + one timed step, after the timed region; bf16 (timed above) sits at the reference's own autocast distance
+            # one warm-up + two timed steps (the faster is reported), after the timed region; bf16 (timed above) sits at the reference's own autocast distance
             def fp32_modes():
                 trainer.compute_dtype = torch.float32
                 res = {}
@@ -465,10 +465,14 @@ def main() -> None:
                     try:                                   # exact: v_mfma_f32_32x32x2_f32, the reference's fp32 arithmetic bit for bit
                         trainer.step(x, a, c, noise, t)
                         torch.cuda.synchronize()
-                        t1 = time.perf_counter()
-                        trainer.step(x, a, c, noise, t)
-                        torch.cuda.synchronize()
-                        res[key] = round(1e3 * (time.perf_counter() - t1), 1)
+                        best = None                        # two timed steps, the faster one: a single step after a mode switch still saw allocator
+                        for _ in range(2):                 # growth on some boxes (x3: 294.5 and 332.7 ms on two boxes of the same tree)
+                            t1 = time.perf_counter()
+                            trainer.step(x, a, c, noise, t)
+                            torch.cuda.synchronize()
+                            dt1 = time.perf_counter() - t1
+                            best = dt1 if best is None else min(best, dt1)
+                        res[key] = round(1e3 * best, 1)
                     finally:
                         ops.set_f32_matmul(prev)
                 return res
